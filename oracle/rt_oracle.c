@@ -1,0 +1,973 @@
+/*
+ * rt_oracle.c -- CPU restatement of the reference hot path (see rt_oracle.h for the
+ * role of this file: TEST INFRASTRUCTURE, parity pinned only by SURVEY.md 8(c) figures).
+ *
+ * Plain C99, IEEE double, build with -O2 -ffp-contract=off (oracle/Makefile).
+ * Reference paths are relative to /root/reference/RayTracing/.
+ *
+ * Deliberate, documented departures from the reference text:
+ *  - unary minus returns by value (the reference returns a reference to a local,
+ *    Geometry.h:90-95, which is UB; intended semantics restated);
+ *  - rand() is replaced by a counter-based generator keyed by
+ *    (pixel, sample, path, light, light-sample, dimension) so that results do not
+ *    depend on evaluation order or thread count;
+ *  - CScene is passed by pointer, not copied per RayTracer call (RayTracer.h:8) --
+ *    a cost difference only.
+ */
+#include "rt_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ constants */
+static const double EPS = 1e-8;          /* Geometry.h:12 */
+static const double PI_REF = 3.1415926535; /* Geometry.h:13 */
+static const double INFTY = 1e+8;        /* Geometry.h:48 */
+
+/* ------------------------------------------------------------------ CPoint3D (Geometry.h:16-138) */
+typedef struct { double x, y, z; } v3;
+typedef struct { double u, v; } v2;
+typedef struct { v3 o, d; } ray_t;       /* CRay, Geometry.h:249-263 */
+typedef struct { v3 mn, mx; } box_t;     /* CBoundingBox, Geometry.h:285-300 */
+
+static inline v3 V3(double x, double y, double z) { v3 r = {x, y, z}; return r; }
+static inline v3 v_add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }       /* :24 */
+static inline v3 v_sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }       /* :25 */
+static inline v3 v_mul(v3 a, double l) { return V3(a.x * l, a.y * l, a.z * l); }         /* :26 */
+static inline v3 v_div(v3 a, double l) { return V3(a.x / l, a.y / l, a.z / l); }         /* :27 */
+static inline v3 v_neg(v3 a) { return V3(-a.x, -a.y, -a.z); }                            /* :90-95, by value */
+static inline v3 v_cross(v3 a, v3 b)                                                      /* :51-56 */
+{ return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static inline double v_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }     /* :121-124 */
+static inline double v_dist2(v3 a, v3 b)                                                  /* :133-138 */
+{ return (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y) + (a.z - b.z) * (a.z - b.z); }
+static inline double v_dist(v3 a, v3 b) { return sqrt(v_dist2(a, b)); }                  /* :126-131 */
+static inline double v_len(v3 a) { return v_dist(a, V3(0, 0, 0)); }                       /* :36 */
+static inline double v_len2(v3 a) { return v_dist2(a, V3(0, 0, 0)); }                     /* :37 */
+static inline int v_eq(v3 a, v3 b)                                                        /* :97-103 */
+{ return fabs(a.x - b.x) < EPS && fabs(a.y - b.y) < EPS && fabs(a.z - b.z) < EPS; }
+static inline v3 infty_pt(void) { return V3(INFTY, INFTY, INFTY); }                       /* :49 */
+static inline int is_infty_pt(v3 a) { return v_eq(a, infty_pt()); }
+static inline v3 v_unitize(v3 a)                                                          /* :113-119 */
+{
+  if (v_eq(a, V3(0, 0, 0)) || is_infty_pt(a)) return infty_pt();
+  return V3(a.x / v_len(a), a.y / v_len(a), a.z / v_len(a));
+}
+static inline ray_t mk_ray(v3 o, v3 d) { ray_t r; r.o = o; r.d = v_unitize(d); return r; } /* :253-254 */
+
+static inline int v2_eq(v2 a, v2 b) { return fabs(a.u - b.u) < EPS && fabs(a.v - b.v) < EPS; } /* :206-212 */
+static inline v2 infty_pt2(void) { v2 r = {INFTY, INFTY}; return r; }                     /* :169 */
+
+/* ------------------------------------------------------------------ CBoundingBox (Geometry.h:302-368) */
+static double box_plane_t(ray_t ray, v3 p0, v3 norm)                                      /* :335-342 */
+{
+  if (fabs(v_dot(norm, ray.d)) < EPS) return INFTY;
+  double D = -v_dot(p0, norm);
+  return -(D + v_dot(norm, ray.o)) / v_dot(norm, ray.d);
+}
+static inline double dmin(double a, double b) { return (b < a) ? b : a; }  /* std::min */
+static inline double dmax(double a, double b) { return (a < b) ? b : a; }  /* std::max */
+
+static v2 box_collide(box_t b, ray_t ray)                                                 /* :302-333 */
+{
+  double t1, t2;
+  t1 = box_plane_t(ray, b.mn, V3(1, 0, 0)); t2 = box_plane_t(ray, b.mx, V3(1, 0, 0));
+  double t_x_min = dmin(t1, t2), t_x_max = dmax(t1, t2);
+  t1 = box_plane_t(ray, b.mn, V3(0, 1, 0)); t2 = box_plane_t(ray, b.mx, V3(0, 1, 0));
+  double t_y_min = dmin(t1, t2), t_y_max = dmax(t1, t2);
+  t1 = box_plane_t(ray, b.mn, V3(0, 0, 1)); t2 = box_plane_t(ray, b.mx, V3(0, 0, 1));
+  double t_z_min = dmin(t1, t2), t_z_max = dmax(t1, t2);
+  double t_max = dmin(dmin(t_x_max, t_y_max), t_z_max);
+  t_x_min = (t_x_min == INFTY) ? -INFTY : t_x_min;
+  t_y_min = (t_y_min == INFTY) ? -INFTY : t_y_min;
+  t_z_min = (t_z_min == INFTY) ? -INFTY : t_z_min;
+  double t_min = dmax(dmax(t_x_min, t_y_min), t_z_min);
+  v2 r;
+  if (t_min < t_max + EPS) { r.u = t_min; r.v = t_max; return r; }
+  return infty_pt2();
+}
+static inline int box_eq(box_t a, box_t b) { return v_eq(a.mn, b.mn) && v_eq(a.mx, b.mx); } /* :344-350 */
+static inline box_t infty_box(void) { box_t b; b.mn = infty_pt(); b.mx = infty_pt(); return b; }
+
+/* ------------------------------------------------------------------ CColour (Colour.h:7-63) */
+typedef struct { double r, g, b; } col_t;
+static inline col_t C3(double r, double g, double b) { col_t c = {r, g, b}; return c; }
+static inline col_t c_add(col_t a, col_t b)                                               /* :26-29, :41-47 */
+{ return C3(dmin(255.0, a.r + b.r), dmin(255.0, a.g + b.g), dmin(255.0, a.b + b.b)); }
+static inline col_t c_mul(col_t a, double w)                                              /* :31-34 */
+{ return C3(dmin(255.0, a.r * w), dmin(255.0, a.g * w), dmin(255.0, a.b * w)); }
+static inline col_t c_div(col_t a, double w)                                              /* :36-39 */
+{ return C3(dmin(255.0, a.r / w), dmin(255.0, a.g / w), dmin(255.0, a.b / w)); }
+
+/* ------------------------------------------------------------------ CMaterial (Material.h:13-124) */
+typedef struct { double reflW, refrW, RI, diff, spec, shiness, emissive, ambient; } mat_t;
+
+void orc_material_preset(int name, double o[8])                                           /* :45-124 */
+{
+  double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  switch (name) {
+    case ORC_MIRROR:    { double t[8] = {1, 0, 0, 0, 1, 2, 0, 0}; memcpy(m, t, sizeof m); } break;
+    case ORC_GLASS:     { double t[8] = {0.05, 0.95, 1.52, 0, 0.05, 20, 0, 0}; memcpy(m, t, sizeof m); } break;
+    case ORC_ICE:       { double t[8] = {0.05, 0.95, 1.31, 0, 0.05, 20, 0, 1}; memcpy(m, t, sizeof m); } break;
+    case ORC_METAL:     { double t[8] = {0.7, 0, 0, 0.2, 0.8, 20, 0, 1}; memcpy(m, t, sizeof m); } break;
+    case ORC_PORCELAIN: { double t[8] = {0.1, 0, 0, 1, 0.1, 2, 0, 1}; memcpy(m, t, sizeof m); } break;
+    case ORC_RUBBER:    { double t[8] = {0, 0, 0, 0.3, 0.4, 1, 0, 1}; memcpy(m, t, sizeof m); } break;
+    case ORC_PLASTIC:   { double t[8] = {0, 0, 0, 0.6, 0.0, 1, 0, 1}; memcpy(m, t, sizeof m); } break;
+    default: break;
+  }
+  memcpy(o, m, sizeof m);
+}
+
+/* ------------------------------------------------------------------ objects (Object.h) */
+typedef struct {
+  int type;                 /* m_type */
+  mat_t mat;
+  col_t colour;
+  box_t aabb;               /* m_AABB, infinite by default (Object.h:34) */
+  /* sphere: c, r ; plane/circle: p0, n (unitized), r */
+  v3 c; double r;
+  v3 p0, n;
+  /* triangle (Object.h:340-344) */
+  v3 vtx[3], vnorm[3], m_norm; int have_vn;
+  /* bezier patch (Object.h:1056-1062) */
+  v3 ctrl[4][4]; v3 center;
+  /* rotational (Object.h:800-808) */
+  v2 prof[8]; int n_prof; int u_sample_num; double u_range;
+} obj_t;
+
+typedef struct { int type; v3 pos_or_dir; double lum; double len; int sample_num; double lum_per_sample; } light_t;
+
+typedef struct bsp_node {                 /* BSPNode, BSPTree.h:20-38 */
+  box_t box;
+  int *objs; int n_objs, cap_objs;
+  int split_axis;
+  struct bsp_node *left, *right;
+} bsp_node;
+
+struct orc_scene {                         /* CScene, Scene.h:12-60 */
+  obj_t *objs; int n_objs, cap_objs;
+  light_t *lights; int n_lights, cap_lights;
+  double ambient;
+  bsp_node *root;
+  int max_obj_num, max_depth;
+};
+
+typedef struct { int64_t rays, nodes, prims, shadow; } counters_t;
+static _Thread_local counters_t *tl_cnt = NULL;
+
+/* ------------------------------------------------------------------ RNG (replaces rand(), Light.h:11) */
+static inline uint64_t mix64(uint64_t z)
+{
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+uint32_t orc_rng_u32(uint64_t seed, uint32_t key0, uint32_t key1, uint32_t counter)
+{
+  uint64_t x = mix64(seed + 0x9E3779B97F4A7C15ULL * ((uint64_t)key0 + 1));
+  x = mix64(x ^ (0xD1B54A32D192ED03ULL * ((uint64_t)key1 + 1)));
+  x = mix64(x ^ (0x8CB92BA72F3D8DD7ULL * ((uint64_t)counter + 1)));
+  return (uint32_t)(x >> 32);
+}
+typedef struct { uint64_t seed; uint32_t pixel, sample, path; } rng_ctx;
+/* counter layout shared with the device code: path(12) | light(4) | light-sample(14) | dim(2) */
+static inline uint32_t rng_counter(uint32_t path, uint32_t light, uint32_t lsample, uint32_t dim)
+{ return (path << 20) | ((light & 15u) << 16) | ((lsample & 0x3FFFu) << 2) | (dim & 3u); }
+/* random(r, x) = 2 r (rand() % x) / x - r, Light.h:11; rand() := 31-bit draw */
+static inline double ref_random(double r, int x, const rng_ctx *g, uint32_t light, uint32_t lsample, uint32_t dim)
+{
+  uint32_t k = orc_rng_u32(g->seed, g->pixel, g->sample, rng_counter(g->path, light, lsample, dim)) >> 1;
+  return 2 * r * (double)(k % (uint32_t)x) / (double)x - r;
+}
+
+/* ------------------------------------------------------------------ scene building */
+orc_scene *orc_scene_new(double ambient)
+{
+  orc_scene *s = (orc_scene *)calloc(1, sizeof *s);
+  s->ambient = ambient;
+  s->max_obj_num = 100; s->max_depth = 40;     /* BSPTree.h:56-57 */
+  return s;
+}
+static void free_node(bsp_node *n)
+{
+  if (!n) return;
+  free_node(n->left); free_node(n->right);
+  free(n->objs); free(n);
+}
+void orc_scene_free(orc_scene *s)
+{
+  if (!s) return;
+  free_node(s->root); free(s->objs); free(s->lights); free(s);
+}
+static obj_t *new_obj(orc_scene *s, int type, const double mat[8], const double col[3])
+{
+  if (s->n_objs == s->cap_objs) {
+    s->cap_objs = s->cap_objs ? s->cap_objs * 2 : 1024;
+    s->objs = (obj_t *)realloc(s->objs, (size_t)s->cap_objs * sizeof(obj_t));
+  }
+  obj_t *o = &s->objs[s->n_objs++];
+  memset(o, 0, sizeof *o);
+  o->type = type;
+  memcpy(&o->mat, mat, sizeof(mat_t));
+  o->colour = C3(col[0], col[1], col[2]);
+  o->aabb = infty_box();                        /* Object.h:34 */
+  return o;
+}
+int orc_num_objects(const orc_scene *s) { return s->n_objs; }
+
+int orc_add_sphere(orc_scene *s, const double c[3], double r, const double mat[8], const double col[3])
+{                                               /* Object.h:229-235 */
+  obj_t *o = new_obj(s, ORC_SPHERE, mat, col);
+  o->c = V3(c[0], c[1], c[2]); o->r = r;
+  o->aabb.mn = v_sub(o->c, V3(r, r, r)); o->aabb.mx = v_add(o->c, V3(r, r, r));
+  return s->n_objs - 1;
+}
+int orc_add_plane(orc_scene *s, const double p0[3], const double n[3], const double mat[8], const double col[3])
+{                                               /* Object.h:685-689 */
+  obj_t *o = new_obj(s, ORC_INFTY_PLANE, mat, col);
+  o->p0 = V3(p0[0], p0[1], p0[2]); o->n = v_unitize(V3(n[0], n[1], n[2]));
+  return s->n_objs - 1;
+}
+int orc_add_circle(orc_scene *s, const double p0[3], const double n[3], double r, const double mat[8], const double col[3])
+{                                               /* Object.h:651-656: no AABB -> infinite */
+  obj_t *o = new_obj(s, ORC_CIRCLE, mat, col);
+  o->p0 = V3(p0[0], p0[1], p0[2]); o->n = v_unitize(V3(n[0], n[1], n[2])); o->r = r;
+  return s->n_objs - 1;
+}
+static void tri_init_aabb(obj_t *o)              /* Object.h:459-468 */
+{
+  double x_min = dmin(dmin(o->vtx[0].x, o->vtx[1].x), o->vtx[2].x);
+  double x_max = dmax(dmax(o->vtx[0].x, o->vtx[1].x), o->vtx[2].x);
+  double y_min = dmin(dmin(o->vtx[0].y, o->vtx[1].y), o->vtx[2].y);
+  double y_max = dmax(dmax(o->vtx[0].y, o->vtx[1].y), o->vtx[2].y);
+  double z_min = dmin(dmin(o->vtx[0].z, o->vtx[1].z), o->vtx[2].z);
+  double z_max = dmax(dmax(o->vtx[0].z, o->vtx[1].z), o->vtx[2].z);
+  o->aabb.mn = V3(x_min - EPS, y_min - EPS, z_min - EPS);
+  o->aabb.mx = V3(x_max + EPS, y_max + EPS, z_max + EPS);
+}
+int orc_add_triangle(orc_scene *s, const double v[9], const double vn[9], const double mat[8], const double col[3])
+{                                               /* Object.h:360-384 */
+  obj_t *o = new_obj(s, ORC_TRIANGLE, mat, col);
+  for (int i = 0; i < 3; i++) o->vtx[i] = V3(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+  o->m_norm = v_unitize(v_cross(v_sub(o->vtx[1], o->vtx[0]), v_sub(o->vtx[2], o->vtx[0])));
+  if (vn) { for (int i = 0; i < 3; i++) o->vnorm[i] = V3(vn[3 * i], vn[3 * i + 1], vn[3 * i + 2]); o->have_vn = 1; }
+  else    { for (int i = 0; i < 3; i++) o->vnorm[i] = o->m_norm; o->have_vn = 0; }
+  tri_init_aabb(o);
+  return s->n_objs - 1;
+}
+int orc_get_triangle(const orc_scene *s, int id, double v[9], double vn[9])
+{
+  if (id < 0 || id >= s->n_objs || s->objs[id].type != ORC_TRIANGLE) return -1;
+  const obj_t *o = &s->objs[id];
+  for (int i = 0; i < 3; i++) {
+    v[3 * i] = o->vtx[i].x; v[3 * i + 1] = o->vtx[i].y; v[3 * i + 2] = o->vtx[i].z;
+    vn[3 * i] = o->vnorm[i].x; vn[3 * i + 1] = o->vnorm[i].y; vn[3 * i + 2] = o->vnorm[i].z;
+  }
+  return o->have_vn;
+}
+
+/* Parser.h:35-82 token loop + Scene.h:150-166 */
+int orc_read_obj_triangle(orc_scene *s, const char *path, const double center[3], double scale,
+                          const double mat[8], const double col[3])
+{
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  size_t np = 0, cp = 0, nn = 0, cn = 0;
+  v3 *pts = NULL, *nrm = NULL;
+  int added = 0;
+  char flag[4096]; flag[0] = 0;
+  v3 ctr = V3(center[0], center[1], center[2]);
+  for (;;) {
+    /* "for (; objStream.good();) { objStream >> objFlag;": a failed extraction leaves objFlag unchanged */
+    int got = fscanf(f, "%4095s", flag);
+    int at_end = (got != 1);
+    if (strcmp(flag, "v") == 0 || strcmp(flag, "vn") == 0) {
+      double x = 0, y = 0, z = 0;
+      if (!at_end) { if (fscanf(f, "%lf", &x) == 1) { if (fscanf(f, "%lf", &y) == 1) { if (fscanf(f, "%lf", &z) != 1) z = 0; } } }
+      if (flag[1] == 0) { if (np == cp) { cp = cp ? cp * 2 : 1024; pts = (v3 *)realloc(pts, cp * sizeof(v3)); } pts[np++] = V3(x, y, z); }
+      else              { if (nn == cn) { cn = cn ? cn * 2 : 1024; nrm = (v3 *)realloc(nrm, cn * sizeof(v3)); } nrm[nn++] = V3(x, y, z); }
+    } else if (strcmp(flag, "vt") == 0) {
+      double u = 0, v = 0;
+      if (!at_end) { if (fscanf(f, "%lf", &u) == 1) { if (fscanf(f, "%lf", &v) != 1) v = 0; } }
+    } else if (strcmp(flag, "f") == 0 && !at_end) {
+      char line[2048];
+      if (!fgets(line, sizeof line, f)) line[0] = 0;
+      int vi[64], ni[64], cnt = 0, pos = 0, a, b, c, rd;
+      while (cnt < 64 && sscanf(line + pos, "%i/%i/%i%n", &a, &b, &c, &rd) == 3) {   /* Parser.h:68 */
+        pos += rd; vi[cnt] = a - 1; ni[cnt] = c - 1; cnt++;
+      }
+      if (cnt != 0) {
+        /* Scene.h:153-165: every face becomes a CTriangle of its first three tuples (4-arg ctor, Object.h:373) */
+        double v[9], vn[9];
+        for (int k = 0; k < 3; k++) {
+          v3 p = v_add(v_mul(pts[vi[k]], scale), ctr);
+          v3 n = nrm[ni[k]];
+          v[3 * k] = p.x; v[3 * k + 1] = p.y; v[3 * k + 2] = p.z;
+          vn[3 * k] = n.x; vn[3 * k + 1] = n.y; vn[3 * k + 2] = n.z;
+        }
+        orc_add_triangle(s, v, vn, mat, col);
+        added++;
+      }
+    }
+    if (at_end) break;
+  }
+  fclose(f); free(pts); free(nrm);
+  return added;
+}
+
+void orc_add_point_light(orc_scene *s, const double pos[3], double lum)
+{
+  if (s->n_lights == s->cap_lights) { s->cap_lights = s->cap_lights ? 2 * s->cap_lights : 8; s->lights = (light_t *)realloc(s->lights, (size_t)s->cap_lights * sizeof(light_t)); }
+  light_t *l = &s->lights[s->n_lights++]; memset(l, 0, sizeof *l);
+  l->type = ORC_POINT_LIGHT; l->pos_or_dir = V3(pos[0], pos[1], pos[2]); l->lum = lum;      /* Light.h:51-52 */
+}
+void orc_add_parallel_light(orc_scene *s, const double dir[3], double lum)
+{
+  if (s->n_lights == s->cap_lights) { s->cap_lights = s->cap_lights ? 2 * s->cap_lights : 8; s->lights = (light_t *)realloc(s->lights, (size_t)s->cap_lights * sizeof(light_t)); }
+  light_t *l = &s->lights[s->n_lights++]; memset(l, 0, sizeof *l);
+  l->type = ORC_PARALLEL_LIGHT; l->pos_or_dir = v_unitize(V3(dir[0], dir[1], dir[2])); l->lum = lum; /* Light.h:76-77 */
+}
+void orc_add_area_light(orc_scene *s, const double pos[3], double lum, double len, int sample_num)
+{
+  if (s->n_lights == s->cap_lights) { s->cap_lights = s->cap_lights ? 2 * s->cap_lights : 8; s->lights = (light_t *)realloc(s->lights, (size_t)s->cap_lights * sizeof(light_t)); }
+  light_t *l = &s->lights[s->n_lights++]; memset(l, 0, sizeof *l);
+  l->type = ORC_AREA_LIGHT; l->pos_or_dir = V3(pos[0], pos[1], pos[2]); l->lum = lum;       /* Light.h:101-108 */
+  l->len = len; l->sample_num = sample_num;
+  l->lum_per_sample = lum / (sample_num * sample_num);
+}
+
+/* ------------------------------------------------------------------ primitive intersection */
+/* Eigen 3.x fixed-size 3x3 determinant (bruteforce_det3_helper), rows m[r][c] */
+static inline double det3(double m00, double m01, double m02,
+                          double m10, double m11, double m12,
+                          double m20, double m21, double m22)
+{
+  return m00 * (m11 * m22 - m12 * m21) - m01 * (m10 * m22 - m12 * m20) + m02 * (m10 * m21 - m11 * m20);
+}
+
+typedef struct { v3 pt; double u, v; } hit_t;    /* point + surface parameters of the recorded hit */
+
+static v3 tri_first_inter_pt(const obj_t *o, ray_t ray)     /* Object.h:416-446 */
+{
+  if (fabs(v_dot(ray.d, o->m_norm)) < EPS) return infty_pt();
+  v3 E1 = v_sub(o->vtx[0], o->vtx[1]);
+  v3 E2 = v_sub(o->vtx[0], o->vtx[2]);
+  v3 S = v_sub(o->vtx[0], ray.o);
+  double dA1 = det3(S.x, E1.x, E2.x, S.y, E1.y, E2.y, S.z, E1.z, E2.z);
+  double dA2 = det3(ray.d.x, S.x, E2.x, ray.d.y, S.y, E2.y, ray.d.z, S.z, E2.z);
+  double dA3 = det3(ray.d.x, E1.x, S.x, ray.d.y, E1.y, S.y, ray.d.z, E1.z, S.z);
+  double dB = det3(ray.d.x, E1.x, E2.x, ray.d.y, E1.y, E2.y, ray.d.z, E1.z, E2.z);
+  double t = dA1 / dB;
+  double belta = dA2 / dB;
+  double gamma = dA3 / dB;
+  if (t > EPS && belta > -EPS && belta < 1 + EPS && gamma > -EPS && gamma < 1 + EPS && belta + gamma < 1 + EPS)
+    return v_add(ray.o, v_mul(ray.d, t));
+  return infty_pt();
+}
+
+static v3 sphere_first_inter_pt(const obj_t *o, ray_t ray)  /* Object.h:250-278 */
+{
+  v3 l = v_sub(o->c, ray.o);
+  double tp = v_dot(l, ray.d);
+  double d2 = v_len2(l) - tp * tp;
+  double radius = o->r;
+  if (d2 > radius * radius + EPS) return infty_pt();
+  double t_prime = sqrt(radius * radius - d2);
+  if (v_len2(l) < radius * radius - EPS) {
+    double t = tp + t_prime;
+    return v_add(ray.o, v_mul(ray.d, t));
+  } else if (v_len2(l) > radius * radius + EPS) {
+    double t = tp - t_prime;
+    if (t > EPS) return v_add(ray.o, v_mul(ray.d, t));
+    return infty_pt();
+  } else {
+    if (tp < EPS) return infty_pt();
+    return v_add(ray.o, v_mul(ray.d, tp * 2));
+  }
+}
+
+static v3 plane_first_inter_pt(const obj_t *o, ray_t ray)   /* Object.h:708-723 */
+{
+  if (fabs(v_dot(o->n, ray.d)) < EPS) {
+    if (fabs(v_dot(v_sub(o->p0, ray.o), o->n)) < EPS) return ray.o;
+    return infty_pt();
+  }
+  double D = -v_dot(o->p0, o->n);
+  double t = -(D + v_dot(o->n, ray.o)) / v_dot(o->n, ray.d);
+  if (t < EPS) return infty_pt();
+  return v_add(ray.o, v_mul(ray.d, t));
+}
+
+static v3 circle_first_inter_pt(const obj_t *o, ray_t ray)  /* Object.h:667-678 */
+{
+  if (fabs(v_dot(o->n, ray.d)) < EPS) return infty_pt();
+  double D = -v_dot(o->p0, o->n);
+  double t = -(D + v_dot(o->n, ray.o)) / v_dot(o->n, ray.d);
+  v3 pt = v_add(ray.o, v_mul(ray.d, t));
+  if (t < EPS || v_dist(pt, o->p0) > o->r - EPS) return infty_pt();
+  return pt;
+}
+
+/* virtual FirstInterPt / FirstInterPt_Unrecorded dispatch (Object.h:37-38) */
+static hit_t obj_first_inter_pt(const obj_t *o, ray_t ray, int record)
+{
+  hit_t h; h.u = INFTY; h.v = INFTY;
+  (void)record;
+  if (tl_cnt) tl_cnt->prims++;
+  switch (o->type) {
+    case ORC_TRIANGLE:    h.pt = tri_first_inter_pt(o, ray); break;
+    case ORC_SPHERE:      h.pt = sphere_first_inter_pt(o, ray); break;
+    case ORC_INFTY_PLANE: h.pt = plane_first_inter_pt(o, ray); break;
+    case ORC_CIRCLE:      h.pt = circle_first_inter_pt(o, ray); break;
+    default:              h.pt = infty_pt(); break;
+  }
+  return h;
+}
+
+/* ------------------------------------------------------------------ normals, reflect/refract, Fresnel */
+static v3 obj_initial_norm(const obj_t *o, v3 pt, double u, double v)
+{
+  (void)u; (void)v;
+  switch (o->type) {
+    case ORC_SPHERE: return v_unitize(v_sub(pt, o->c));                                   /* Object.h:239 */
+    case ORC_TRIANGLE: {                                                                  /* Object.h:448-457 */
+      if (!o->have_vn) return o->m_norm;
+      double S0 = v_len(v_cross(v_sub(o->vtx[1], pt), v_sub(o->vtx[2], pt)));
+      double S1 = v_len(v_cross(v_sub(o->vtx[0], pt), v_sub(o->vtx[2], pt)));
+      double S2 = v_len(v_cross(v_sub(o->vtx[0], pt), v_sub(o->vtx[1], pt)));
+      double S = v_len(v_cross(v_sub(o->vtx[1], o->vtx[0]), v_sub(o->vtx[2], o->vtx[0])));
+      return v_add(v_add(v_mul(o->vnorm[0], S0 / S), v_mul(o->vnorm[1], S1 / S)), v_mul(o->vnorm[2], S2 / S));
+    }
+    case ORC_CIRCLE: case ORC_INFTY_PLANE: return o->n;                                   /* Object.h:660,693 */
+    default: return infty_pt();
+  }
+}
+/* CBaseObject::Norm without bump texture, Object.h:79-83 */
+static v3 obj_norm(const obj_t *o, v3 pt, double u, double v) { return obj_initial_norm(o, pt, u, v); }
+
+static ray_t obj_reflect_ray(const obj_t *o, ray_t ray, v3 pt, double u, double v)        /* Object.h:94-101 */
+{
+  v3 N = obj_norm(o, pt, u, v);
+  if (v_dot(ray.d, N) > EPS) N = v_neg(N);
+  v3 dir = v_sub(ray.d, v_mul(N, 2 * v_dot(ray.d, N)));
+  return mk_ray(pt, v_unitize(dir));
+}
+static ray_t obj_refract_ray(const obj_t *o, ray_t ray, v3 pt, double u, double v)        /* Object.h:103-126 */
+{
+  v3 N = obj_norm(o, pt, u, v);
+  v3 T = infty_pt();
+  if (v_dot(ray.d, N) < EPS) {
+    double ni_nt = 1 / o->mat.RI;
+    double cos_theta_i2 = v_dot(ray.d, N) * v_dot(ray.d, N);
+    double cos_theta_t = sqrt(1 - ni_nt * ni_nt * (1 - cos_theta_i2));
+    T = v_add(v_mul(N, ni_nt * v_dot(v_neg(ray.d), N) - cos_theta_t), v_mul(ray.d, ni_nt));
+  } else {
+    N = v_neg(N);
+    double ni_nt = o->mat.RI;
+    double cos_theta_i2 = v_dot(ray.d, N) * v_dot(ray.d, N);
+    if (1 - ni_nt * ni_nt * (1 - cos_theta_i2) > EPS) {
+      double cos_theta_t = sqrt(1 - ni_nt * ni_nt * (1 - cos_theta_i2));
+      T = v_add(v_mul(N, ni_nt * v_dot(v_neg(ray.d), N) - cos_theta_t), v_mul(ray.d, ni_nt));
+    }
+  }
+  return mk_ray(pt, v_unitize(T));
+}
+/* common part of reflW/refrW(ray, pt), Object.h:128-184: returns (r_p^2 + r_v^2)/2 */
+static double fresnel_R(const obj_t *o, ray_t ray, v3 pt, double u, double v)
+{
+  v3 N = obj_norm(o, pt, u, v);
+  double ni_nt = 0, cos_theta_i = 0, cos_theta_t = 0;
+  if (v_dot(ray.d, N) < EPS) {
+    ni_nt = 1 / o->mat.RI;
+    double cos_theta_i2 = v_dot(ray.d, N) * v_dot(ray.d, N);
+    cos_theta_i = sqrt(cos_theta_i2);
+    cos_theta_t = sqrt(1 - ni_nt * ni_nt * (1 - cos_theta_i2));
+  } else {
+    N = v_neg(N);
+    ni_nt = o->mat.RI;
+    double cos_theta_i2 = v_dot(ray.d, N) * v_dot(ray.d, N);
+    cos_theta_i = sqrt(cos_theta_i2);
+    if (1 - ni_nt * ni_nt * (1 - cos_theta_i2) > EPS)
+      cos_theta_t = sqrt(1 - ni_nt * ni_nt * (1 - cos_theta_i2));
+  }
+  double r_p = (ni_nt * cos_theta_i - cos_theta_t) / (ni_nt * cos_theta_i + cos_theta_t);
+  double r_v = (cos_theta_i - ni_nt * cos_theta_t) / (cos_theta_i + ni_nt * cos_theta_t);
+  return (r_p * r_p + r_v * r_v) / 2;
+}
+static double obj_reflW(const obj_t *o, ray_t ray, v3 pt, double u, double v)             /* Object.h:128-155 */
+{
+  if (o->mat.reflW == 0 || o->mat.refrW == 0) return o->mat.reflW;
+  return fresnel_R(o, ray, pt, u, v);
+}
+static double obj_refrW(const obj_t *o, ray_t ray, v3 pt, double u, double v)             /* Object.h:157-184 */
+{
+  if (o->mat.reflW == 0 || o->mat.refrW == 0) return o->mat.refrW;
+  return 1 - fresnel_R(o, ray, pt, u, v);
+}
+
+/* ------------------------------------------------------------------ BSP tree build (BSPTree.h:58-109) */
+static int obj_point_in_box(const obj_t *o, box_t box)       /* Object.h:212-222 */
+{
+  if (box_eq(box, infty_box())) return 1;
+  box_t b = o->aabb;
+  if (b.mn.x > box.mx.x + EPS || b.mx.x < box.mn.x - EPS ||
+      b.mn.y > box.mx.y + EPS || b.mx.y < box.mn.y - EPS ||
+      b.mn.z > box.mx.z + EPS || b.mx.z < box.mn.z - EPS)
+    return 0;
+  return 1;
+}
+static bsp_node *new_node(box_t box)
+{
+  bsp_node *n = (bsp_node *)calloc(1, sizeof *n);
+  n->box = box; n->split_axis = -1;
+  return n;
+}
+static void node_push(bsp_node *n, int id)
+{
+  if (n->n_objs == n->cap_objs) { n->cap_objs = n->cap_objs ? n->cap_objs * 2 : 16; n->objs = (int *)realloc(n->objs, (size_t)n->cap_objs * sizeof(int)); }
+  n->objs[n->n_objs++] = id;
+}
+static void subdivide(orc_scene *s, bsp_node *node, int depth, int cur_axis)
+{
+  if (node->n_objs < s->max_obj_num || depth == s->max_depth) return;       /* :60 */
+  node->split_axis = cur_axis;
+  int next_axis = 0;
+  box_t left, right;
+  v3 mn = node->box.mn, mx = node->box.mx;
+  if (cur_axis == 0) {                                                          /* :69-76 */
+    left.mn = mn; left.mx = V3((mn.x + mx.x) / 2, mx.y, mx.z);
+    right.mn = V3((mn.x + mx.x) / 2, mn.y, mn.z); right.mx = mx;
+    next_axis = 1;
+  } else if (cur_axis == 1) {                                                   /* :77-84 */
+    left.mn = mn; left.mx = V3(mx.x, (mn.y + mx.y) / 2, mx.z);
+    right.mn = V3(mn.x, (mn.y + mx.y) / 2, mn.z); right.mx = mx;
+    next_axis = 2;
+  } else {                                                                      /* :85-92 */
+    left.mn = mn; left.mx = V3(mx.x, mx.y, (mn.z + mx.z) / 2);
+    right.mn = V3(mn.x, mn.y, (mn.z + mx.z) / 2); right.mx = mx;
+    next_axis = 0;
+  }
+  node->left = new_node(left); node->right = new_node(right);
+  int *infty_objs = NULL; int n_inf = 0, cap_inf = 0;
+  for (int i = 0; i < node->n_objs; i++) {                                      /* :94-102 */
+    int id = node->objs[i];
+    const obj_t *o = &s->objs[id];
+    if (obj_point_in_box(o, left)) node_push(node->left, id);
+    if (obj_point_in_box(o, right)) node_push(node->right, id);
+    if (node == s->root && box_eq(o->aabb, infty_box())) {
+      if (n_inf == cap_inf) { cap_inf = cap_inf ? cap_inf * 2 : 8; infty_objs = (int *)realloc(infty_objs, (size_t)cap_inf * sizeof(int)); }
+      infty_objs[n_inf++] = id;
+    }
+  }
+  free(node->objs); node->objs = NULL; node->n_objs = node->cap_objs = 0;      /* :103 */
+  if (node == s->root) { node->objs = infty_objs; node->n_objs = node->cap_objs = n_inf; } /* :104-105 */
+  else free(infty_objs);
+  subdivide(s, node->left, depth + 1, next_axis);
+  subdivide(s, node->right, depth + 1, next_axis);
+}
+static box_t biggest_aabb(const orc_scene *s)                /* Scene.h:295-317 */
+{
+  double x_min = INFTY, x_max = -INFTY, y_min = INFTY, y_max = -INFTY, z_min = INFTY, z_max = -INFTY;
+  for (int i = 0; i < s->n_objs; i++) {
+    box_t b = s->objs[i].aabb;
+    if (box_eq(b, infty_box())) continue;
+    if (b.mn.x < x_min) x_min = b.mn.x;
+    if (b.mn.y < y_min) y_min = b.mn.y;
+    if (b.mn.z < z_min) z_min = b.mn.z;
+    if (b.mx.x > x_max) x_max = b.mx.x;
+    if (b.mx.y > y_max) y_max = b.mx.y;
+    if (b.mx.z > z_max) z_max = b.mx.z;
+  }
+  if (x_min != INFTY && y_min != INFTY && z_min != INFTY && x_max != -INFTY && y_max != -INFTY && z_max != INFTY) {
+    box_t r; r.mn = V3(x_min, y_min, z_min); r.mx = V3(x_max, y_max, z_max); return r;
+  }
+  return infty_box();
+}
+void orc_construct_bsp(orc_scene *s, int max_obj_num, int max_depth)  /* Scene.h:286-293 */
+{
+  free_node(s->root); s->root = NULL;
+  s->max_obj_num = max_obj_num > 0 ? max_obj_num : 100;
+  s->max_depth = max_depth > 0 ? max_depth : 40;
+  box_t big = biggest_aabb(s);
+  if (box_eq(big, infty_box())) return;
+  s->root = new_node(big);
+  for (int i = 0; i < s->n_objs; i++) node_push(s->root, i);
+  subdivide(s, s->root, 0, 0);
+}
+static void stats_rec(const bsp_node *n, int depth, int64_t st[8], int is_root)
+{
+  st[0]++;
+  if (depth > st[4]) st[4] = depth;
+  if (!n->left && !n->right) {
+    st[1]++;
+    if (n->n_objs == 0) st[2]++;
+    st[3] += n->n_objs;
+    if (n->n_objs > st[5]) st[5] = n->n_objs;
+  } else {
+    (void)is_root;
+    stats_rec(n->left, depth + 1, st, 0); stats_rec(n->right, depth + 1, st, 0);
+  }
+}
+void orc_tree_stats(const orc_scene *s, int64_t st[8], double root_box[6])
+{
+  memset(st, 0, 8 * sizeof(int64_t));
+  if (!s->root) return;
+  st[7] = 1;
+  stats_rec(s->root, 0, st, 1);
+  st[6] = (s->root->left || s->root->right) ? s->root->n_objs : 0;
+  if (root_box) {
+    root_box[0] = s->root->box.mn.x; root_box[1] = s->root->box.mn.y; root_box[2] = s->root->box.mn.z;
+    root_box[3] = s->root->box.mx.x; root_box[4] = s->root->box.mx.y; root_box[5] = s->root->box.mx.z;
+  }
+}
+
+/* ------------------------------------------------------------------ closest hit (Scene.h:62-91, 319-432) */
+typedef struct { v3 pt; int obj; double u, v; } inter_t;     /* CIntersection, Scene.h:23-28 */
+static inline inter_t no_inter(void) { inter_t r; r.pt = infty_pt(); r.obj = -1; r.u = r.v = INFTY; return r; }
+
+/* the candidate-update block repeated at Scene.h:65-81, 329-346, 352-368, 369-386 */
+static inline void consider(orc_scene *s, int id, ray_t ray, int record, inter_t *best)
+{
+  hit_t h = obj_first_inter_pt(&s->objs[id], ray, record);
+  if (!is_infty_pt(h.pt)) {
+    if (is_infty_pt(best->pt) || v_dist(h.pt, ray.o) < v_dist(best->pt, ray.o) - EPS) {
+      best->pt = h.pt; best->obj = id; best->u = h.u; best->v = h.v;
+    }
+  }
+}
+static inter_t first_inter_pt(orc_scene *s, ray_t ray, int record)     /* Scene.h:62-83 */
+{
+  inter_t best = no_inter();
+  for (int i = 0; i < s->n_objs; i++) consider(s, i, ray, record, &best);
+  return best;
+}
+static double scene_plane_t(ray_t ray, v3 p0, v3 norm)                /* Scene.h:421-432 */
+{
+  if (fabs(v_dot(norm, ray.d)) < EPS) {
+    if (fabs(v_dot(v_sub(p0, ray.o), norm)) <= EPS) return 0;
+    return INFTY;
+  }
+  double D = -v_dot(p0, norm);
+  return -(D + v_dot(norm, ray.o)) / v_dot(norm, ray.d);
+}
+static inter_t ray_tree_intersect(orc_scene *s, ray_t ray, bsp_node *node, int record)   /* Scene.h:319-419 */
+{
+  if (tl_cnt) tl_cnt->nodes++;
+  v2 tmm = box_collide(node->box, ray);
+  double t_min = tmm.u, t_max = tmm.v;
+  if (v2_eq(tmm, infty_pt2())) {                                         /* :326-348 */
+    inter_t best = no_inter();
+    for (int i = 0; i < s->root->n_objs; i++) consider(s, s->root->objs[i], ray, record, &best);
+    return best;
+  }
+  if (!node->left && !node->right) {                                     /* :349-388 */
+    inter_t best = no_inter();
+    for (int i = 0; i < node->n_objs; i++) consider(s, node->objs[i], ray, record, &best);
+    for (int i = 0; i < s->root->n_objs; i++) consider(s, s->root->objs[i], ray, record, &best);
+    return best;
+  }
+  v3 p0 = v_div(v_add(node->box.mn, node->box.mx), 2);                   /* :389 */
+  v3 normal = V3(0, 0, 0);
+  if (node->split_axis == 0) normal.x = 1;
+  if (node->split_axis == 1) normal.y = 1;
+  if (node->split_axis == 2) normal.z = 1;
+  double dist = scene_plane_t(ray, p0, normal);
+  bsp_node *near_n, *far_n;
+  if (v_dot(v_sub(p0, ray.o), normal) > 0) { near_n = node->left; far_n = node->right; }
+  else { near_n = node->right; far_n = node->left; }
+  if (dist > t_max + EPS || dist < -EPS)                                  /* :406 */
+    return ray_tree_intersect(s, ray, near_n, record);
+  else if (dist < t_min - EPS && fabs(dist) > EPS)                        /* :408 */
+    return ray_tree_intersect(s, ray, far_n, record);
+  else {
+    inter_t i1 = ray_tree_intersect(s, ray, near_n, record);
+    inter_t i2 = ray_tree_intersect(s, ray, far_n, record);
+    if (v_dist2(i1.pt, ray.o) < v_dist2(i2.pt, ray.o) - EPS) return i1;   /* :414 */
+    return i2;
+  }
+}
+static inter_t first_inter_pt_bsp(orc_scene *s, ray_t ray, int record)  /* Scene.h:85-91 */
+{
+  if (tl_cnt) tl_cnt->rays++;
+  if (!s->root) return first_inter_pt(s, ray, record);
+  return ray_tree_intersect(s, ray, s->root, record);
+}
+
+/* ------------------------------------------------------------------ lights (Light.h, Scene.h:436-455) */
+static v3 light_direction(const light_t *l, v3 pt)
+{
+  if (l->type == ORC_PARALLEL_LIGHT) return l->pos_or_dir;               /* Light.h:80 */
+  return v_unitize(v_sub(pt, l->pos_or_dir));                            /* Light.h:55,111 */
+}
+static double light_luminosity(orc_scene *s, const light_t *l, int light_idx, v3 pt, const rng_ctx *g)
+{
+  if (l->type == ORC_POINT_LIGHT) {                                      /* Light.h:34-44 + 62-69 */
+    for (int i = 0; i < s->n_objs; i++) {
+      ray_t ray = mk_ray(pt, v_sub(l->pos_or_dir, pt));
+      if (tl_cnt) tl_cnt->shadow++;
+      v3 ip = obj_first_inter_pt(&s->objs[i], ray, 0).pt;
+      if (!is_infty_pt(ip) && v_dot(v_sub(pt, ip), v_sub(l->pos_or_dir, ip)) < -EPS) return 0;
+    }
+    return l->lum;
+  }
+  if (l->type == ORC_PARALLEL_LIGHT) {                                   /* Light.h:34-44 + 87-94 */
+    for (int i = 0; i < s->n_objs; i++) {
+      ray_t ray = mk_ray(pt, v_neg(l->pos_or_dir));
+      if (tl_cnt) tl_cnt->shadow++;
+      v3 ip = obj_first_inter_pt(&s->objs[i], ray, 0).pt;
+      if (!is_infty_pt(ip)) return 0;
+    }
+    return l->lum;
+  }
+  /* area light: Scene.h:436-455 (tree) or Light.h:126-162 (no tree) */
+  double L = 0;
+  int sn = l->sample_num;
+  double r = (l->len / (double)sn) / 2;
+  v3 O = V3(l->pos_or_dir.x - sn * r, l->pos_or_dir.y - sn * r, l->pos_or_dir.z);
+  for (int i = 0; i < sn; i++) {
+    for (int j = 0; j < sn; j++) {
+      double x0 = O.x + i * r * 2, y0 = O.y + j * r * 2, z0 = O.z;
+      uint32_t ls = (uint32_t)(i * sn + j);
+      /* draw order pinned: x first, then y */
+      double rx = ref_random(r, 1000, g, (uint32_t)light_idx, ls, 0);
+      double ry = ref_random(r, 1000, g, (uint32_t)light_idx, ls, 1);
+      v3 sample_pt = V3(x0 + rx, y0 + ry, z0);
+      ray_t ray = mk_ray(pt, v_sub(sample_pt, pt));
+      if (tl_cnt) tl_cnt->shadow++;
+      if (s->root) {                                                      /* Scene.h:448-451 */
+        v3 ip = first_inter_pt_bsp(s, ray, 0).pt;
+        if (!is_infty_pt(ip) && v_dot(v_sub(pt, ip), v_sub(l->pos_or_dir, ip)) < -EPS) continue;
+        L += l->lum_per_sample;
+      } else {                                                            /* Light.h:152-162 + 143-150 */
+        double Ls = l->lum_per_sample;
+        for (int k = 0; k < s->n_objs; k++) {
+          v3 ip = obj_first_inter_pt(&s->objs[k], ray, 0).pt;
+          if (!is_infty_pt(ip) && v_dot(v_sub(pt, ip), v_sub(l->pos_or_dir, ip)) < -EPS) { Ls = 0; break; }
+        }
+        L += Ls;
+      }
+    }
+  }
+  return L;
+}
+
+/* ------------------------------------------------------------------ shading (Scene.h:93-122, RayTracer.h:8-55) */
+static col_t local_illumination(orc_scene *s, ray_t ray, inter_t in, const rng_ctx *g)
+{
+  const obj_t *o = &s->objs[in.obj];
+  col_t colour = C3(0, 0, 0);
+  v3 norm = obj_norm(o, in.pt, in.u, in.v);
+  if (v_dot(ray.d, norm) > EPS) norm = v_neg(norm);
+  col_t obj_colour = o->colour;                                          /* Object.h:186-189, untextured */
+  for (int li = 0; li < s->n_lights; li++) {
+    const light_t *l = &s->lights[li];
+    double L = light_luminosity(s, l, li, in.pt, g);
+    ray_t reflect = obj_reflect_ray(o, ray, in.pt, in.u, in.v);
+    double emissive = o->mat.emissive;
+    v3 ldir = light_direction(l, in.pt);
+    double diffuse = o->mat.diff * dmax(0.0, -v_dot(norm, ldir) * L);
+    double specular = o->mat.spec * L * pow(dmax(0.0, -v_dot(ldir, reflect.d)), o->mat.shiness);
+    colour = c_add(colour, c_mul(obj_colour, emissive + s->ambient * o->mat.ambient + diffuse + specular));
+  }
+  return colour;
+}
+
+static const double THRESHOLD = 0.1;                                      /* RayTracer.h:7 */
+static col_t ray_tracer(orc_scene *s, ray_t ray, int depth, double weight, col_t bg, rng_ctx g,
+                        int32_t *first_id)
+{
+  col_t colour = C3(0, 0, 0);
+  if (weight < THRESHOLD) return bg;
+  inter_t in = first_inter_pt_bsp(s, ray, 1);
+  if (first_id) *first_id = in.obj;
+  if (in.obj < 0) return bg;
+  const obj_t *o = &s->objs[in.obj];
+  colour = local_illumination(s, ray, in, &g);
+  if (depth > 1) {
+    int total_reflect = 0;
+    double refrW = obj_refrW(o, ray, in.pt, in.u, in.v);
+    double reflW = obj_reflW(o, ray, in.pt, in.u, in.v);
+    if (refrW != 0) {
+      ray_t rr = obj_refract_ray(o, ray, in.pt, in.u, in.v);
+      if (!is_infty_pt(rr.d)) {
+        rng_ctx g2 = g; g2.path = g.path * 2;
+        col_t rc = ray_tracer(s, rr, depth - 1, weight * refrW, bg, g2, NULL);
+        colour = c_add(colour, c_mul(rc, refrW));
+      } else total_reflect = 1;
+    }
+    if (reflW != 0) {
+      ray_t rl = obj_reflect_ray(o, ray, in.pt, in.u, in.v);
+      rng_ctx g2 = g; g2.path = g.path * 2 + 1;
+      if (!total_reflect) {
+        col_t rc = ray_tracer(s, rl, depth - 1, weight * reflW, bg, g2, NULL);
+        colour = c_add(colour, c_mul(rc, reflW));
+      } else {
+        col_t rc = ray_tracer(s, rl, depth - 1, weight * (reflW + refrW), bg, g2, NULL);
+        colour = c_add(colour, c_mul(rc, reflW + refrW));
+      }
+    }
+  }
+  return colour;
+}
+
+/* ------------------------------------------------------------------ camera (Camera.h:17-28, 53-75, 171-199) */
+typedef struct { v3 view_pt, eye, center, up, left, start; double hor, ver; int res, depth, W, H; } cam_t;
+static cam_t cam_init(const orc_camera *c)
+{
+  cam_t k;
+  v3 v_eye = V3(c->eye_dir[0], c->eye_dir[1], c->eye_dir[2]);
+  v3 v_left = V3(c->left_arg[0], c->left_arg[1], c->left_arg[2]);
+  k.view_pt = V3(c->view_pt[0], c->view_pt[1], c->view_pt[2]);
+  k.eye = v_unitize(v_eye);
+  k.up = v_unitize(v_cross(v_left, v_eye));                               /* :19, un-normalised eye */
+  k.left = v_unitize(v_cross(k.up, k.eye));                               /* :21 */
+  k.hor = c->hor_range; k.ver = c->ver_range; k.res = c->resolution; k.depth = c->depth;
+  k.center = v_add(k.view_pt, v_mul(k.eye, c->dist_of_plane));            /* :27 */
+  k.W = (int)(k.hor * k.res); k.H = (int)(k.ver * k.res);                 /* :55-56 */
+  k.start = v_add(v_add(k.center, v_mul(k.left, k.hor / 2)), v_mul(k.up, k.ver / 2)); /* :57 */
+  return k;
+}
+static inline v3 cam_cur_pt(const cam_t *k, int h, int v)                 /* :65 */
+{
+  return v_sub(v_sub(k->start, v_mul(k->left, (double)h / (double)k->res)), v_mul(k->up, (double)v / (double)k->res));
+}
+void orc_camera_size(const orc_camera *c, int *w, int *h) { cam_t k = cam_init(c); *w = k.W; *h = k.H; }
+void orc_camera_rays(const orc_camera *c, double *rays)
+{
+  cam_t k = cam_init(c);
+  for (int v = 0; v < k.H; v++)
+    for (int h = 0; h < k.W; h++) {
+      v3 cur = cam_cur_pt(&k, h, v);
+      ray_t r = mk_ray(k.view_pt, v_unitize(v_sub(cur, k.view_pt)));       /* :67 */
+      double *o = rays + ((size_t)v * k.W + h) * 6;
+      o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+    }
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static void add_counters(int64_t *dst, const counters_t *c)
+{
+  if (!dst) return;
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+  { dst[0] += c->rays; dst[1] += c->nodes; dst[2] += c->prims; dst[3] += c->shadow; }
+}
+
+void orc_render_whitted(orc_scene *s, const orc_camera *c, const double bg[3], uint64_t seed,
+                        double *rgb, int32_t *prim_id, size_t first, size_t count, int threads,
+                        int64_t *counters)
+{
+  cam_t k = cam_init(c);
+  size_t total = (size_t)k.W * k.H;
+  if (count == 0) { first = 0; count = total; }
+  col_t bgc = C3(bg[0], bg[1], bg[2]);
+  if (counters) memset(counters, 0, 4 * sizeof(int64_t));
+#ifdef _OPENMP
+  int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nt)
+#endif
+  {
+    counters_t cnt = {0, 0, 0, 0};
+    tl_cnt = counters ? &cnt : NULL;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 256)
+#endif
+    for (long long p = (long long)first; p < (long long)(first + count); p++) {
+      int v = (int)(p / k.W), h = (int)(p % k.W);
+      v3 cur = cam_cur_pt(&k, h, v);
+      ray_t ray = mk_ray(k.view_pt, v_unitize(v_sub(cur, k.view_pt)));     /* Camera.h:67 */
+      rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = 0; g.path = 1;
+      int32_t id = -1;
+      col_t col = ray_tracer(s, ray, k.depth, 1, bgc, g, &id);             /* :68 */
+      size_t q = (size_t)p - first;
+      rgb[3 * q] = col.r; rgb[3 * q + 1] = col.g; rgb[3 * q + 2] = col.b;
+      if (prim_id) prim_id[q] = id;
+    }
+    tl_cnt = NULL;
+    if (counters) add_counters(counters, &cnt);
+  }
+  (void)threads;
+}
+
+void orc_render_focusing(orc_scene *s, const orc_camera *c, double radius, int spp, const double bg[3],
+                         uint64_t seed, double *rgb, size_t first, size_t count, int threads,
+                         int64_t *counters)
+{
+  cam_t k = cam_init(c);
+  size_t total = (size_t)k.W * k.H;
+  if (count == 0) { first = 0; count = total; }
+  col_t bgc = C3(bg[0], bg[1], bg[2]);
+  if (counters) memset(counters, 0, 4 * sizeof(int64_t));
+#ifdef _OPENMP
+  int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nt)
+#endif
+  {
+    counters_t cnt = {0, 0, 0, 0};
+    tl_cnt = counters ? &cnt : NULL;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 64)
+#endif
+    for (long long p = (long long)first; p < (long long)(first + count); p++) {
+      int v = (int)(p / k.W), h = (int)(p % k.W);
+      v3 cur = cam_cur_pt(&k, h, v);
+      col_t colour = C3(0, 0, 0);
+      for (int i = 0; i < spp; i++) {                                      /* Camera.h:187-192 */
+        rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = (uint32_t)i; g.path = 0;
+        /* lens draws: path 0, dims 0,1,2 = x,y,z (draw order pinned x,y,z) */
+        double jx = ref_random(radius, 1000, &g, 0, 0, 0);
+        double jy = ref_random(radius, 1000, &g, 0, 0, 1);
+        double jz = ref_random(radius, 1000, &g, 0, 0, 2);
+        v3 pnt = V3(k.view_pt.x + jx, k.view_pt.y + jy, k.view_pt.z + jz);
+        ray_t ray = mk_ray(pnt, v_unitize(v_sub(cur, pnt)));
+        g.path = 1;
+        col_t sc = ray_tracer(s, ray, k.depth, 1, bgc, g, NULL);
+        colour = c_add(colour, c_div(sc, spp));
+      }
+      size_t q = (size_t)p - first;
+      rgb[3 * q] = colour.r; rgb[3 * q + 1] = colour.g; rgb[3 * q + 2] = colour.b;
+    }
+    tl_cnt = NULL;
+    if (counters) add_counters(counters, &cnt);
+  }
+  (void)threads;
+}
+
+/* ------------------------------------------------------------------ batch queries for tests */
+void orc_trace_closest(orc_scene *s, const double *rays, size_t n, int use_bsp, int record,
+                       int32_t *out_id, double *out_pt, double *out_uv)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256)
+#endif
+  for (long long i = 0; i < (long long)n; i++) {
+    const double *r = rays + 6 * i;
+    ray_t ray = mk_ray(V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]));
+    inter_t in = use_bsp ? first_inter_pt_bsp(s, ray, record) : first_inter_pt(s, ray, record);
+    out_id[i] = in.obj;
+    if (out_pt) { out_pt[3 * i] = in.pt.x; out_pt[3 * i + 1] = in.pt.y; out_pt[3 * i + 2] = in.pt.z; }
+    if (out_uv) { out_uv[2 * i] = in.u; out_uv[2 * i + 1] = in.v; }
+  }
+}
+
+void orc_object_first_inter_pt(orc_scene *s, int id, const double r[6], double out_pt[3], double out_uv[2])
+{
+  ray_t ray = mk_ray(V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]));
+  hit_t h = obj_first_inter_pt(&s->objs[id], ray, 1);
+  out_pt[0] = h.pt.x; out_pt[1] = h.pt.y; out_pt[2] = h.pt.z;
+  if (out_uv) { out_uv[0] = h.u; out_uv[1] = h.v; }
+}
