@@ -1,0 +1,204 @@
+/*
+ * rt_hip.h -- C ABI of the MI355X (gfx950) ray-scene hot path.
+ *
+ * The reference renderer (FlyingGiraffe/ray_tracing) has no FFI: its seams are C++
+ * member calls inside one translation unit.  This header is the boundary that the
+ * reference-shaped C++ host layer (ray_tracing_amd/host/) calls instead of those
+ * members.  Each entry point cites the reference call it replaces; paths are relative
+ * to /root/reference/RayTracing/.
+ *
+ * Conventions
+ *  - plain C, POD structs with explicit sizes, no C++ or torch types;
+ *  - every function returns RT_HIP_OK (0) or a negative RT_HIP_E* code and never
+ *    throws or aborts; rt_hip_last_error() gives the text for the calling thread;
+ *  - host-pointer entry points are synchronous: inputs are copied during the call and
+ *    outputs are complete on return;
+ *  - *_dev entry points take DEVICE pointers plus a hipStream_t (passed as void*), only
+ *    enqueue work on that stream and return; the caller synchronises;
+ *  - one context = one GPU; one process per GPU is the intended multi-GPU model (the
+ *    pixel / sample range arguments of the render calls are the sharding hooks; the
+ *    exchange of the shards is done by the caller, e.g. RCCL all-reduce / all-gather);
+ *  - a context and its scenes may be used by one thread at a time;
+ *  - there is NO CPU fallback: without a usable HIP device every call fails with
+ *    RT_HIP_EHIP.
+ *
+ * Numeric contract (all arithmetic IEEE double, constants of Geometry.h:12-13,48):
+ *  - primitive ids are indices into CScene::objects (Scene.h:18), -1 = miss;
+ *  - an accepted hit's t is computed with the reference's own operation order
+ *    (e.g. Object.h:416-446 for triangles), so it is bit-identical to a CPU build of
+ *    the reference formula; the BSP walk is front-to-back with early exit, which can
+ *    differ from the reference's exhaustive walk (Scene.h:406-418) only in which of
+ *    two hits closer than 1e-8 to each other is reported.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_HIP_OK            0
+#define RT_HIP_EINVAL       (-1)  /* bad argument / inconsistent scene description */
+#define RT_HIP_EHIP         (-2)  /* HIP runtime error or no device */
+#define RT_HIP_ENOMEM       (-3)
+#define RT_HIP_EUNSUPPORTED (-4)
+
+/* object types, values of Object.h:17-23 */
+#define RT_HIP_SPHERE      0
+#define RT_HIP_TRIANGLE    1
+#define RT_HIP_POLYGON     2   /* not supported: no layout uses CPolygon */
+#define RT_HIP_CIRCLE      3
+#define RT_HIP_INFTY_PLANE 4
+#define RT_HIP_ROTATIONAL  5
+#define RT_HIP_BEZIER      6
+/* light types, values of Light.h:7-9 */
+#define RT_HIP_POINT_LIGHT    100
+#define RT_HIP_PARALLEL_LIGHT 101
+#define RT_HIP_AREA_LIGHT     102
+
+typedef struct rt_hip_ctx   rt_hip_ctx;
+typedef struct rt_hip_scene rt_hip_scene;
+
+/* CRay (Geometry.h:249-263).  d need not be unit length: like the CRay constructor the
+ * library normalises it (Geometry.h:253-254). */
+typedef struct { double o[3]; double d[3]; } rt_hip_ray;                 /* 48 B */
+
+/* CScene::CIntersection (Scene.h:23-28) in parametric form: the hit point is
+ * o + d*t for sphere/triangle/circle/plane.  u,v: surface parameters for
+ * Bezier/rotational objects (cur_u/cur_v of Object.h:805-808), else 1e8. */
+typedef struct { double t; double u; double v; int32_t prim_id; int32_t reserved; } rt_hip_hit;  /* 32 B */
+
+typedef struct { double v[3][3]; double vn[3][3]; int32_t has_vn; int32_t reserved; } rt_hip_triangle; /* CTriangle, Object.h:340-344 */
+typedef struct { double p0[3]; double n[3]; } rt_hip_plane;              /* CInftyPlane; n already unitized (Object.h:686) */
+typedef struct { double c[3]; double r; } rt_hip_sphere;                 /* CSphere, Object.h:246-247 */
+typedef struct { double p0[3]; double n[3]; double r; } rt_hip_circle;   /* CCircle; n already unitized (Object.h:652) */
+/* CMaterial, Material.h:33-42 */
+typedef struct { double reflW, refrW, RI, diff, spec, shiness, emissive, ambient; } rt_hip_material;
+/* CPointLight / CParallelLight / CAreaLight (Light.h:48-124).  pos_or_dir: position, or the
+ * already unitized direction of a parallel light (Light.h:77). */
+typedef struct { int32_t type; int32_t sample_num; double pos_or_dir[3]; double luminosity; double len; } rt_hip_light;
+
+/* Flattened BSPNode (BSPTree.h:20-38), 64 B.  split_axis = -1 for a leaf (then a = first index
+ * into refs[], b = number of refs), else 0/1/2 (then a = left child, b = right child). */
+typedef struct {
+  double box_min[3]; double box_max[3];
+  int32_t split_axis; int32_t a; int32_t b; int32_t reserved;
+} rt_hip_node;
+
+/* Everything CScene holds that the hot path reads (Scene.h:17-21), flattened by the host. */
+typedef struct {
+  uint32_t struct_size;            /* sizeof(rt_hip_scene_desc), for versioning */
+  uint32_t n_objects;              /* CScene::objects.size(); prim id = index */
+  const uint8_t  *obj_type;        /* [n_objects] RT_HIP_* type */
+  const uint32_t *obj_index;       /* [n_objects] index into the array of that type */
+  const uint32_t *obj_material;    /* [n_objects] index into materials */
+  const double   *obj_colour;      /* [n_objects][3] m_colour R,G,B (Object.h:67) */
+  uint32_t n_triangles; const rt_hip_triangle *triangles;
+  uint32_t n_planes;    const rt_hip_plane    *planes;
+  uint32_t n_spheres;   const rt_hip_sphere   *spheres;
+  uint32_t n_circles;   const rt_hip_circle   *circles;
+  uint32_t n_materials; const rt_hip_material *materials;
+  uint32_t n_lights;    const rt_hip_light    *lights;
+  double ambient;                  /* CScene::ambient */
+  /* BSP tree as built by BSPTree::Subdivide; n_nodes == 0 means "no tree" (Scene.h:87-88) */
+  uint32_t n_nodes;     const rt_hip_node *nodes;      /* nodes[0] = root */
+  uint32_t n_refs;      const uint32_t    *refs;       /* leaf object lists, prim ids */
+  uint32_t n_root_objects; const uint32_t *root_objects; /* bspTree.root->objects after the build (BSPTree.h:104-105) */
+} rt_hip_scene_desc;
+
+/* CCamera constructor arguments (Camera.h:17-18) */
+typedef struct {
+  double view_pt[3]; double eye_dir[3]; double left[3];
+  double dist_of_plane; double hor_range; double ver_range;
+  int32_t resolution; int32_t depth;
+} rt_hip_camera;
+
+/* Run-time values of what the reference fixes at compile time. */
+typedef struct {
+  uint32_t struct_size;
+  double   background[3];   /* RayTracer's background argument (RayTracer.h:8) */
+  double   weight_threshold;/* 0 -> 0.1 (RayTracer.h:7) */
+  uint64_t seed;            /* counter-based generator standing in for rand() (Light.h:11) */
+  uint32_t spp;             /* Render_Focusing samples per pixel; 0 -> 100 (Camera.h:171) */
+  double   lens_radius;     /* Render_Focusing radius argument */
+  uint64_t pixel_first;     /* shard of the v*W+h raster to render; pixel_count 0 = all */
+  uint64_t pixel_count;
+  uint32_t sample_first;    /* shard of the spp loop; sample_count 0 = all */
+  uint32_t sample_count;
+  uint32_t collect_stats;   /* non-zero: count node visits / primitive tests (slower kernels) */
+  uint32_t reserved;
+} rt_hip_params;
+
+typedef struct {
+  uint64_t rays;            /* closest-hit + occlusion queries */
+  uint64_t shadow_rays;     /* occlusion queries among them */
+  uint64_t node_visits;     /* per ray (lane) box tests */
+  uint64_t prim_tests;      /* per ray (lane) primitive cull tests */
+  uint64_t exact_tests;     /* per ray (lane) reference-arithmetic confirmations */
+  uint64_t wave_node_visits;/* per wave node pops */
+  uint64_t wave_prim_tests; /* per wave primitive iterations */
+  uint64_t reserved;
+} rt_hip_stats;
+
+/* ---- context / errors ------------------------------------------------------------ */
+int rt_hip_device_count(int *n);
+int rt_hip_context_create(int device_id, rt_hip_ctx **out);
+int rt_hip_context_destroy(rt_hip_ctx *ctx);
+const char *rt_hip_last_error(void);
+/* counters accumulated by calls made with collect_stats != 0; reset = 1 clears them */
+int rt_hip_get_stats(rt_hip_ctx *ctx, rt_hip_stats *out, int reset);
+
+/* ---- scene: replaces CScene::ConstructBSPTree's product (Scene.h:286-293) ----------- */
+/* Copies the description to the device (replicated per GPU) and derives the traversal
+ * layout.  leaf_refine > 0 lets the library split the reference's leaves further (same
+ * spatial-median rule, BSPTree.h:58-109) down to that many objects -- an acceleration
+ * detail that does not change any result; 0 keeps the reference tree as is. */
+int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *desc, uint32_t leaf_refine, rt_hip_scene **out);
+int rt_hip_scene_destroy(rt_hip_scene *scene);
+
+/* ---- queries --------------------------------------------------------------------- */
+/* CScene::FirstInterPt_BSPTree(ray, record) (Scene.h:85-91) for n rays.
+ * use_tree = 0 forces CScene::FirstInterPt (brute force, Scene.h:62-83). */
+int rt_hip_trace_closest(rt_hip_scene *scene, const rt_hip_ray *rays, size_t n, int use_tree, int record,
+                         rt_hip_hit *hits);
+int rt_hip_trace_closest_dev(rt_hip_scene *scene, const rt_hip_ray *d_rays, size_t n, int use_tree, int record,
+                             rt_hip_hit *d_hits, uint32_t collect_stats, void *stream);
+
+/* The shadow predicate of CAreaLight::luminosity_BSPTree (Scene.h:447-450) /
+ * CPointLight::InShadow (Light.h:62-69): occluded[i] = 1 iff some object is hit at a point X with
+ * Dot(o - X, ref_pts[i] - X) < -eps; with ref_pts == NULL the CParallelLight rule
+ * (any hit at all, Light.h:87-94) applies. */
+int rt_hip_trace_occluded(rt_hip_scene *scene, const rt_hip_ray *rays, const double *ref_pts, size_t n,
+                          int use_tree, uint8_t *occluded);
+
+/* ---- renders --------------------------------------------------------------------- */
+/* image size of a camera: int(horRange*resolution) x int(verRange*resolution) (Camera.h:55-56) */
+int rt_hip_camera_size(const rt_hip_camera *cam, int *width, int *height);
+
+/* CCamera::Render_RayTracer (Camera.h:53-75) up to, not including, the uchar store:
+ * rgb[(v*W+h)*3 + {0,1,2}] = colour.R(),G(),B() as doubles; prim_id (optional) = primary hit id.
+ * With a pixel shard in params the outputs hold pixel_count entries. */
+int rt_hip_render_whitted(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
+                          double *rgb, int32_t *prim_id);
+int rt_hip_render_whitted_dev(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
+                              double *d_rgb, int32_t *d_prim_id, void *stream);
+
+/* CCamera::Render_Focusing (Camera.h:171-199): spp lens samples per pixel.  The output is the SUM over
+ * the sample shard of sample_colour/spp WITHOUT the running clamp, so that shards add up
+ * (all-reduce) and one final min(255, .) gives the reference's clamped running sum (every term
+ * is >= 0, Colour.h:41-47). */
+int rt_hip_render_focusing(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
+                           double *rgb);
+int rt_hip_render_focusing_dev(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
+                               double *d_rgb, void *stream);
+
+/* number of rays (closest-hit + occlusion queries) issued by the last render call on this scene */
+int rt_hip_last_ray_count(rt_hip_scene *scene, uint64_t *rays, uint64_t *shadow_rays);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

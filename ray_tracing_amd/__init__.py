@@ -1,0 +1,322 @@
+"""ray_tracing_amd -- Python harness over the MI355X ray-scene hot path.
+
+The product is native: ``lib/librt_hip.so`` (hand-written gfx950 kernels behind the ``rt_hip_*``
+C ABI of ``include/rt_hip.h``) and ``lib/librt_host.so`` (the C++ host layer that mirrors the
+reference's CScene / CCamera interface).  This module only binds them with ctypes so that tests
+and ``bench.py`` can drive them; it computes nothing and has NO fallback: importing it without
+the built libraries raises, and every call without a GPU fails with RT_HIP_EHIP.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBDIR = os.path.join(_HERE, "lib")
+
+
+def _load(name):
+    path = os.path.join(_LIBDIR, name)
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: run `python __graft_entry__.py` (hipcc) first; there is no CPU fallback" % path)
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+hip = _load("librt_hip.so")     # the C ABI (include/rt_hip.h)
+host = _load("librt_host.so")   # C++ host layer, flat entry points (host/rt_host_capi.cpp)
+
+d3 = C.c_double * 3
+d8 = C.c_double * 8
+
+# ---- ABI structs (include/rt_hip.h) -------------------------------------------------------------
+RAY_DTYPE = np.dtype([("o", "f8", 3), ("d", "f8", 3)])
+HIT_DTYPE = np.dtype([("t", "f8"), ("u", "f8"), ("v", "f8"), ("prim_id", "i4"), ("reserved", "i4")])
+NODE_DTYPE = np.dtype([("box_min", "f8", 3), ("box_max", "f8", 3), ("split_axis", "i4"), ("a", "i4"), ("b", "i4"), ("reserved", "i4")])
+TRI_DTYPE = np.dtype([("v", "f8", (3, 3)), ("vn", "f8", (3, 3)), ("has_vn", "i4"), ("reserved", "i4")])
+assert RAY_DTYPE.itemsize == 48 and HIT_DTYPE.itemsize == 32 and NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 152
+
+
+class CameraStruct(C.Structure):
+    _fields_ = [("view_pt", d3), ("eye_dir", d3), ("left", d3), ("dist_of_plane", C.c_double), ("hor_range", C.c_double),
+                ("ver_range", C.c_double), ("resolution", C.c_int32), ("depth", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("background", d3), ("weight_threshold", C.c_double), ("seed", C.c_uint64),
+                ("spp", C.c_uint32), ("lens_radius", C.c_double), ("pixel_first", C.c_uint64), ("pixel_count", C.c_uint64),
+                ("sample_first", C.c_uint32), ("sample_count", C.c_uint32), ("collect_stats", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def __init__(self, background=(0, 0, 0), seed=0, **kw):
+        super().__init__()
+        self.struct_size = C.sizeof(Params)
+        self.background = d3(*background)
+        self.seed = seed
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "shadow_rays", "node_visits", "prim_tests", "exact_tests",
+                                          "wave_node_visits", "wave_prim_tests", "reserved")]
+
+
+hip.rt_hip_last_error.restype = C.c_char_p
+host.rth_last_error.restype = C.c_char_p
+host.rth_context_raw.restype = C.c_void_p
+host.rth_num_objects.restype = C.c_size_t
+host.rth_tree_arrays.restype = C.c_size_t
+host.rth_triangles.restype = C.c_size_t
+host.rth_camera_rgb.restype = C.POINTER(C.c_double)
+host.rth_camera_prim_id.restype = C.POINTER(C.c_int32)
+host.rth_camera_image.restype = C.POINTER(C.c_uint8)
+host.rth_camera_raw.restype = C.POINTER(CameraStruct)
+
+# explicit prototypes where pointers / 64-bit values are passed
+_vp = C.c_void_p
+host.rth_context_new.argtypes = [C.c_int, C.POINTER(_vp)]
+host.rth_context_free.argtypes = [_vp]
+host.rth_context_raw.argtypes = [_vp]
+host.rth_scene_new.argtypes = [C.c_double, C.POINTER(_vp)]
+host.rth_scene_free.argtypes = [_vp]
+host.rth_material_preset.argtypes = [C.c_int, d8]
+host.rth_add_sphere.argtypes = [_vp, d3, C.c_double, d8, d3]
+host.rth_add_plane.argtypes = [_vp, d3, d3, d8, d3]
+host.rth_add_circle.argtypes = [_vp, d3, d3, C.c_double, d8, d3]
+host.rth_add_triangle.argtypes = [_vp, _vp, _vp, d8, d3]
+host.rth_add_triangles.argtypes = [_vp, _vp, C.c_size_t, d8, d3]
+host.rth_read_obj_triangle.argtypes = [_vp, C.c_char_p, d3, C.c_double, d8, d3, C.POINTER(C.c_int)]
+host.rth_add_point_light.argtypes = [_vp, d3, C.c_double]
+host.rth_add_parallel_light.argtypes = [_vp, d3, C.c_double]
+host.rth_add_area_light.argtypes = [_vp, d3, C.c_double, C.c_double, C.c_int]
+host.rth_construct_bsp.argtypes = [_vp, C.c_int, C.c_int]
+host.rth_set_leaf_refine.argtypes = [_vp, C.c_uint]
+host.rth_num_objects.argtypes = [_vp]
+host.rth_tree_stats.argtypes = [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+host.rth_tree_arrays.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_size_t)]
+host.rth_triangles.argtypes = [_vp, C.POINTER(_vp)]
+host.rth_scene_device.argtypes = [_vp, _vp, C.POINTER(_vp)]
+host.rth_first_inter_pt.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp]
+host.rth_camera_new.argtypes = [d3, d3, d3, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(_vp)]
+host.rth_camera_free.argtypes = [_vp]
+host.rth_camera_size.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+host.rth_camera_seed.argtypes = [_vp, C.c_uint64]
+host.rth_camera_raw.argtypes = [_vp]
+host.rth_render_raytracer.argtypes = [_vp, _vp, _vp, d3]
+host.rth_render_focusing.argtypes = [_vp, _vp, _vp, C.c_double, d3, C.c_uint]
+host.rth_camera_rgb.argtypes = [_vp]
+host.rth_camera_prim_id.argtypes = [_vp]
+host.rth_camera_image.argtypes = [_vp]
+host.rth_camera_write_ppm.argtypes = [_vp, C.c_char_p]
+
+hip.rt_hip_device_count.argtypes = [C.POINTER(C.c_int)]
+hip.rt_hip_get_stats.argtypes = [_vp, C.POINTER(Stats), C.c_int]
+hip.rt_hip_trace_closest.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp]
+hip.rt_hip_trace_closest_dev.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp, C.c_uint32, _vp]
+hip.rt_hip_trace_occluded.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]
+hip.rt_hip_camera_size.argtypes = [C.POINTER(CameraStruct), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
+hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
+hip.rt_hip_render_focusing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp]
+hip.rt_hip_render_focusing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
+hip.rt_hip_last_ray_count.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rt_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _chk_host(rc):
+    if rc != 0:
+        raise RtError(rc, host.rth_last_error().decode(errors="replace"))
+
+
+def check(rc):
+    """raise for a failed rt_hip_* call"""
+    if rc != 0:
+        raise RtError(rc, hip.rt_hip_last_error().decode(errors="replace"))
+
+
+MATERIALS = {"mirror": 200, "glass": 201, "ice": 202, "metal": 203, "porcelain": 204, "rubber": 205, "plastic": 206}
+
+
+def material(name):
+    """CMaterial preset (Material.h:45-124) as 8 doubles"""
+    m = d8()
+    host.rth_material_preset(MATERIALS[name] if isinstance(name, str) else int(name), m)
+    return m
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = hip.rt_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context:
+    def __init__(self, device=0):
+        self._h = _vp()
+        _chk_host(host.rth_context_new(device, C.byref(self._h)))
+
+    @property
+    def raw(self):
+        return host.rth_context_raw(self._h)
+
+    def stats(self, reset=True):
+        s = Stats()
+        check(hip.rt_hip_get_stats(self.raw, C.byref(s), 1 if reset else 0))
+        return {n: getattr(s, n) for n, _ in Stats._fields_ if n != "reserved"}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host.rth_context_free(self._h)
+            self._h = None
+
+
+class Scene:
+    """rt::host::Scene (the CScene mirror)"""
+
+    def __init__(self, ambient=0.0):
+        self._h = _vp()
+        _chk_host(host.rth_scene_new(float(ambient), C.byref(self._h)))
+
+    def add_sphere(self, c, r, mat, colour):
+        return host.rth_add_sphere(self._h, d3(*c), r, mat, d3(*colour))
+
+    def add_plane(self, p0, n, mat, colour):
+        return host.rth_add_plane(self._h, d3(*p0), d3(*n), mat, d3(*colour))
+
+    def add_circle(self, p0, n, r, mat, colour):
+        return host.rth_add_circle(self._h, d3(*p0), d3(*n), r, mat, d3(*colour))
+
+    def add_triangle(self, v, vn, mat, colour):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(9)
+        vnp = None
+        if vn is not None:
+            vn = np.ascontiguousarray(vn, dtype=np.float64).reshape(9)
+            vnp = vn.ctypes.data
+        return host.rth_add_triangle(self._h, v.ctypes.data, vnp, mat, d3(*colour))
+
+    def add_triangles(self, v, mat, colour):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, 9)
+        _chk_host(host.rth_add_triangles(self._h, v.ctypes.data, v.shape[0], mat, d3(*colour)))
+
+    def read_obj_triangle(self, path, center, scale, mat, colour):
+        n = C.c_int(0)
+        _chk_host(host.rth_read_obj_triangle(self._h, os.fsencode(path), d3(*center), scale, mat, d3(*colour), C.byref(n)))
+        return n.value
+
+    def add_point_light(self, p, lum):
+        host.rth_add_point_light(self._h, d3(*p), lum)
+
+    def add_parallel_light(self, d, lum):
+        host.rth_add_parallel_light(self._h, d3(*d), lum)
+
+    def add_area_light(self, p, lum, length, sample_num):
+        host.rth_add_area_light(self._h, d3(*p), lum, length, sample_num)
+
+    def construct_bsp(self, max_obj_num=0, max_depth=0):
+        _chk_host(host.rth_construct_bsp(self._h, max_obj_num, max_depth))
+
+    def set_leaf_refine(self, n):
+        host.rth_set_leaf_refine(self._h, n)
+
+    @property
+    def num_objects(self):
+        return host.rth_num_objects(self._h)
+
+    def tree_stats(self):
+        st = (C.c_longlong * 8)()
+        box = (C.c_double * 6)()
+        host.rth_tree_stats(self._h, st, box)
+        return list(st), list(box)
+
+    def tree_arrays(self):
+        nodes, refs, nr = _vp(), _vp(), C.c_size_t(0)
+        nn = host.rth_tree_arrays(self._h, C.byref(nodes), C.byref(refs), C.byref(nr))
+        if nn == 0:
+            return np.zeros(0, NODE_DTYPE), np.zeros(0, np.uint32)
+        n = np.ctypeslib.as_array(C.cast(nodes, C.POINTER(C.c_uint8)), shape=(nn * 64,)).view(NODE_DTYPE).copy()
+        r = np.ctypeslib.as_array(C.cast(refs, C.POINTER(C.c_uint32)), shape=(nr.value,)).copy() if nr.value else np.zeros(0, np.uint32)
+        return n, r
+
+    def triangles(self):
+        t = _vp()
+        n = host.rth_triangles(self._h, C.byref(t))
+        if n == 0:
+            return np.zeros(0, TRI_DTYPE)
+        return np.ctypeslib.as_array(C.cast(t, C.POINTER(C.c_uint8)), shape=(n * 152,)).view(TRI_DTYPE).copy()
+
+    def device(self, ctx):
+        """rt_hip_scene* for direct ABI calls (uploads on first use)"""
+        raw = _vp()
+        _chk_host(host.rth_scene_device(self._h, ctx._h, C.byref(raw)))
+        return raw
+
+    def first_inter_pt(self, ctx, rays, use_tree=True, record=True):
+        """CScene::FirstInterPt_BSPTree / FirstInterPt for an (n,6) array of rays"""
+        r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        hits = np.zeros(r.shape[0], HIT_DTYPE)
+        _chk_host(host.rth_first_inter_pt(self._h, ctx._h, r.ctypes.data, r.shape[0], int(use_tree), int(record), hits.ctypes.data))
+        return hits
+
+    def occluded(self, ctx, rays, ref_pts=None, use_tree=True):
+        r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        out = np.zeros(r.shape[0], np.uint8)
+        rp = None
+        if ref_pts is not None:
+            ref_pts = np.ascontiguousarray(ref_pts, dtype=np.float64).reshape(-1, 3)
+            assert ref_pts.shape[0] == r.shape[0]
+            rp = ref_pts.ctypes.data
+        check(hip.rt_hip_trace_occluded(self.device(ctx), r.ctypes.data, rp, r.shape[0], int(use_tree), out.ctypes.data))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host.rth_scene_free(self._h)
+            self._h = None
+
+
+class Camera:
+    """rt::host::Camera (the CCamera mirror)"""
+
+    def __init__(self, view, eye, left, dist, hor, ver, res, depth):
+        self._h = _vp()
+        _chk_host(host.rth_camera_new(d3(*view), d3(*eye), d3(*left), dist, hor, ver, res, depth, C.byref(self._h)))
+        w, h = C.c_int(), C.c_int()
+        host.rth_camera_size(self._h, C.byref(w), C.byref(h))
+        self.width, self.height = w.value, h.value
+
+    @property
+    def raw(self):
+        return host.rth_camera_raw(self._h)
+
+    def set_seed(self, seed):
+        host.rth_camera_seed(self._h, seed)
+
+    def render_raytracer(self, ctx, scene, background=(0, 0, 0)):
+        _chk_host(host.rth_render_raytracer(self._h, ctx._h, scene._h, d3(*background)))
+
+    def render_focusing(self, ctx, scene, radius, background=(0, 0, 0), spp=100):
+        _chk_host(host.rth_render_focusing(self._h, ctx._h, scene._h, radius, d3(*background), spp))
+
+    def rgb(self):
+        n = self.width * self.height
+        return np.ctypeslib.as_array(host.rth_camera_rgb(self._h), shape=(n, 3)).copy()
+
+    def prim_id(self):
+        p = host.rth_camera_prim_id(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.width * self.height,)).copy()
+
+    def image(self):
+        return np.ctypeslib.as_array(host.rth_camera_image(self._h), shape=(self.height, self.width, 3)).copy()
+
+    def write_ppm(self, path):
+        _chk_host(host.rth_camera_write_ppm(self._h, os.fsencode(path)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host.rth_camera_free(self._h)
+            self._h = None

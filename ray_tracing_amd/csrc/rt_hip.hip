@@ -1,0 +1,942 @@
+// rt_hip.hip -- gfx950 kernels and the C ABI of include/rt_hip.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.build()).
+// -ffp-contract=off keeps the reference's rounding in every formula that is restated from it; the
+// triangle cull uses explicit fma() where speed matters and exactness does not.
+//
+// There is no CPU fallback in this file: every entry point needs a HIP device.
+#include "../../include/rt_hip.h"
+#include "rt_device.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rt;
+
+// ================================================================================================
+// errors
+// ================================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(RT_HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+
+extern "C" const char *rt_hip_last_error(void) { return g_err.c_str(); }
+
+// ================================================================================================
+// host-side objects
+// ================================================================================================
+struct DevBuf {
+  void *p = nullptr; size_t bytes = 0;
+  int ensure(size_t need)
+  {
+    if (need <= bytes) return RT_HIP_OK;
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    size_t cap = need + need / 4 + 4096;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) { p = nullptr; return fail(RT_HIP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    bytes = cap;
+    return RT_HIP_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct rt_hip_ctx {
+  int device = 0;
+  Stats *d_stats = nullptr;      // accumulated counters
+};
+
+// one node of the ray tree of a pixel sample (level arrays of the wavefront Whitted integrator)
+struct alignas(16) PathNode {
+  double o[3], d[3];
+  double t, weight;
+  double col[3];
+  double w_refr, w_refl;
+  int32_t id; uint32_t pixel; uint32_t sample; uint32_t path;
+  int32_t child_refr, child_refl;   // >= 0 index in the next level, -1 none, -2 background (weight cut, RayTracer.h:11)
+};
+static_assert(sizeof(PathNode) == 128, "PathNode layout");
+
+struct rt_hip_scene {
+  rt_hip_ctx *ctx = nullptr;
+  DevScene dev{};
+  std::vector<void *> allocs;     // scene arrays
+  // render workspace (grow-only, reused between calls)
+  static constexpr int kMaxLevels = 16;
+  DevBuf levels[kMaxLevels];
+  DevBuf counter;                 // queue counter + per-render ray counters
+  DevBuf staging;                 // host-pointer entry points
+  uint64_t last_rays = 0, last_shadow = 0;
+  // tree statistics after refinement (for tests / DESIGN)
+  uint32_t n_nodes = 0, n_leaves = 0, n_cull = 0, max_depth = 0;
+};
+
+struct RenderCounters { unsigned int queue_count; unsigned int pad; unsigned long long rays; unsigned long long shadow_rays; };
+
+// ================================================================================================
+// scene preparation (host)
+// ================================================================================================
+namespace {
+
+struct Box { double mn[3], mx[3]; };
+
+struct Builder {
+  const rt_hip_scene_desc *d;
+  uint32_t leaf_refine;
+  std::vector<Box> aabb;            // per object (finite ones)
+  std::vector<uint8_t> finite;
+  std::vector<DNode> nodes;
+  std::vector<TriCull> cull;
+  std::vector<int32_t> leaf_other;
+  std::vector<TriExact> tri_exact;
+  uint32_t n_leaves = 0, max_depth = 0;
+  std::string err;
+
+  // object AABBs as the reference builds them: CTriangle::InitializeAABB (Object.h:459-468),
+  // CSphere ctor (Object.h:234); planes and circles keep the infinite default (Object.h:34)
+  void object_boxes()
+  {
+    aabb.resize(d->n_objects); finite.assign(d->n_objects, 0);
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+      uint32_t k = d->obj_index[i];
+      Box b;
+      if (d->obj_type[i] == RT_HIP_TRIANGLE) {
+        const rt_hip_triangle &t = d->triangles[k];
+        for (int a = 0; a < 3; a++) {
+          b.mn[a] = std::min(std::min(t.v[0][a], t.v[1][a]), t.v[2][a]) - kEps;
+          b.mx[a] = std::max(std::max(t.v[0][a], t.v[1][a]), t.v[2][a]) + kEps;
+        }
+        finite[i] = 1;
+      } else if (d->obj_type[i] == RT_HIP_SPHERE) {
+        const rt_hip_sphere &s = d->spheres[k];
+        for (int a = 0; a < 3; a++) { b.mn[a] = s.c[a] - s.r; b.mx[a] = s.c[a] + s.r; }
+        finite[i] = 1;
+      } else {
+        for (int a = 0; a < 3; a++) { b.mn[a] = kInfty; b.mx[a] = kInfty; }
+      }
+      aabb[i] = b;
+    }
+  }
+  // CBaseObject::PointInBox, Object.h:212-222
+  bool overlaps(uint32_t id, const Box &box) const
+  {
+    const Box &b = aabb[id];
+    for (int a = 0; a < 3; a++)
+      if (b.mn[a] > box.mx[a] + kEps || b.mx[a] < box.mn[a] - kEps) return false;
+    return true;
+  }
+
+  TriCull make_cull(uint32_t prim, uint32_t tri) const
+  {
+    TriCull c; std::memset(&c, 0, sizeof c);
+    c.prim_id = (int32_t)prim; c.tri_idx = (int32_t)tri;
+    const TriExact &T = tri_exact[tri];
+    V3 v0 = mk(T.v0[0], T.v0[1], T.v0[2]), v1 = mk(T.v1[0], T.v1[1], T.v1[2]), v2 = mk(T.v2[0], T.v2[1], T.v2[2]);
+    V3 n = mk(T.nrm[0], T.nrm[1], T.nrm[2]);
+    V3 e1 = v1 - v0, e2 = v2 - v0;
+    V3 N = cross(e1, e2);
+    double nn = dot(N, N);
+    double l1 = len(e1), l2 = len(e2);
+    bool ok = std::isfinite(nn) && nn > 0 && !is_infty_pt(n) && std::isfinite(n.x) && l1 > 0 && l2 > 0;
+    double sinv = ok ? (l1 * l2) / std::sqrt(nn) : 1e30;   // 1/sin(angle at v0)
+    if (!ok || sinv > 1e3) return c;                       // n = 0: always confirm
+    // dual basis: beta = dot(P - v0, B), gamma = dot(P - v0, G) with B = (e2 x N)/|N|^2, G = (N x e1)/|N|^2
+    V3 B = cross(e2, N) / nn, G = cross(N, e1) / nn;
+    c.n[0] = n.x; c.n[1] = n.y; c.n[2] = n.z; c.dpl = dot(v0, n);
+    c.B[0] = B.x; c.B[1] = B.y; c.B[2] = B.z; c.b0 = -dot(v0, B);
+    c.G[0] = G.x; c.G[1] = G.y; c.G[2] = G.z; c.g0 = -dot(v0, G);
+    c.bsum = std::fabs(B.x) + std::fabs(B.y) + std::fabs(B.z) + std::fabs(G.x) + std::fabs(G.y) + std::fabs(G.z) + sinv;
+    if (!std::isfinite(c.bsum) || !std::isfinite(c.b0) || !std::isfinite(c.g0)) { TriCull z; std::memset(&z, 0, sizeof z); z.prim_id = c.prim_id; z.tri_idx = c.tri_idx; return z; }
+    return c;
+  }
+
+  // emits a leaf for the object list `objs` in kd cell `cell`; returns node index or -1 if empty
+  int emit_leaf(const std::vector<uint32_t> &objs, const Box &cell, uint32_t depth)
+  {
+    if (objs.empty()) return -1;
+    DNode nd; std::memset(&nd, 0, sizeof nd);
+    Box u; for (int a = 0; a < 3; a++) { u.mn[a] = 1e300; u.mx[a] = -1e300; }
+    int first_c = (int)cull.size(), first_o = (int)leaf_other.size(), n_other = 0;
+    for (uint32_t id : objs) {
+      for (int a = 0; a < 3; a++) { u.mn[a] = std::min(u.mn[a], aabb[id].mn[a]); u.mx[a] = std::max(u.mx[a], aabb[id].mx[a]); }
+      if (d->obj_type[id] == RT_HIP_TRIANGLE) cull.push_back(make_cull(id, d->obj_index[id]));
+      else { leaf_other.push_back((int32_t)id); n_other++; }
+    }
+    for (int a = 0; a < 3; a++) {
+      // every hit point of a referenced object inside this cell lies in cell /\ union(AABB)
+      nd.bmin[a] = std::max(cell.mn[a], u.mn[a]) - kBoxPad;
+      nd.bmax[a] = std::min(cell.mx[a], u.mx[a]) + kBoxPad;
+    }
+    nd.axis = -1 - n_other; nd.a = first_c; nd.b = (int)cull.size() - first_c; nd.c = first_o;
+    nodes.push_back(nd);
+    n_leaves++; max_depth = std::max(max_depth, depth);
+    return (int)nodes.size() - 1;
+  }
+  int emit_inner(int axis, int l, int r, uint32_t depth)
+  {
+    if (l < 0) return r;
+    if (r < 0) return l;
+    DNode nd; std::memset(&nd, 0, sizeof nd);
+    for (int a = 0; a < 3; a++) {
+      nd.bmin[a] = std::min(nodes[l].bmin[a], nodes[r].bmin[a]);
+      nd.bmax[a] = std::max(nodes[l].bmax[a], nodes[r].bmax[a]);
+    }
+    nd.axis = axis; nd.a = l; nd.b = r;
+    nodes.push_back(nd);
+    max_depth = std::max(max_depth, depth);
+    return (int)nodes.size() - 1;
+  }
+  // continues BSPTree::Subdivide (BSPTree.h:58-109) below a reference leaf, down to leaf_refine objects
+  int refine(std::vector<uint32_t> &objs, const Box &cell, uint32_t depth)
+  {
+    if (leaf_refine == 0 || objs.size() < leaf_refine || depth >= 56) return emit_leaf(objs, cell, depth);
+    int axis = (int)(depth % 3);
+    Box L = cell, R = cell;
+    double mid = (cell.mn[axis] + cell.mx[axis]) / 2;
+    L.mx[axis] = mid; R.mn[axis] = mid;
+    std::vector<uint32_t> lo, ro;
+    for (uint32_t id : objs) { if (overlaps(id, L)) lo.push_back(id); if (overlaps(id, R)) ro.push_back(id); }
+    // stop when the split no longer separates anything (all objects straddle the plane)
+    if (lo.size() == objs.size() && ro.size() == objs.size()) return emit_leaf(objs, cell, depth);
+    std::vector<uint32_t>().swap(objs);
+    int l = refine(lo, L, depth + 1);
+    int r = refine(ro, R, depth + 1);
+    return emit_inner(axis, l, r, depth);
+  }
+  // walks the reference tree of the description
+  int walk(uint32_t ni, uint32_t depth)
+  {
+    if (ni >= d->n_nodes) { err = "node index out of range"; return -1; }
+    const rt_hip_node &n = d->nodes[ni];
+    Box cell; for (int a = 0; a < 3; a++) { cell.mn[a] = n.box_min[a]; cell.mx[a] = n.box_max[a]; }
+    if (depth > 56) { err = "tree deeper than 56 levels"; return -1; }
+    if (n.split_axis < 0) {
+      if (n.a < 0 || n.b < 0 || (uint64_t)n.a + (uint64_t)n.b > d->n_refs) { err = "leaf ref range out of bounds"; return -1; }
+      std::vector<uint32_t> objs;
+      for (int i = 0; i < n.b; i++) {
+        uint32_t id = d->refs[n.a + i];
+        if (id >= d->n_objects) { err = "leaf ref out of range"; return -1; }
+        if (finite[id]) objs.push_back(id);   // infinite objects only reach the device through root_objects
+      }
+      return refine(objs, cell, depth);
+    }
+    if (n.split_axis > 2 || n.a <= (int)ni || n.b <= (int)ni) { err = "bad inner node"; return -1; }
+    int l = walk((uint32_t)n.a, depth + 1);
+    if (!err.empty()) return -1;
+    int r = walk((uint32_t)n.b, depth + 1);
+    if (!err.empty()) return -1;
+    return emit_inner(n.split_axis, l, r, depth);
+  }
+};
+
+template <class T>
+int upload(rt_hip_scene *s, const std::vector<T> &v, const T **out)
+{
+  *out = nullptr;
+  if (v.empty()) return RT_HIP_OK;
+  void *p = nullptr;
+  HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
+  s->allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T *)p;
+  return RT_HIP_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// kernels
+// ================================================================================================
+#define RT_BLOCK 256
+#define RT_WAVES (RT_BLOCK / 64)
+
+struct DevCamera {
+  V3 view_pt, start, left, up;
+  int res, W, H, depth;
+};
+
+__device__ __forceinline__ void stats_flush(Stats *g, const Stats &s)
+{
+  if (!g) return;
+  // per-lane counters -> one atomic per lane is too many: reduce over the wave first
+  unsigned long long v[7] = {s.rays, s.shadow_rays, s.node_visits, s.prim_tests, s.exact_tests, s.wave_nodes, s.wave_prims};
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    unsigned long long x = v[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(((unsigned long long *)g) + k, x);
+  }
+}
+
+// XCD-aware block remap: consecutive hardware block ids go round-robin over the 8 XCDs (each with its
+// own L2); give every XCD one contiguous range of work items instead of a stride-8 comb.
+__device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int nb)
+{
+  const unsigned int q = nb / 8, r = nb % 8, x = b % 8, i = b / 8;
+  const unsigned int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + i;
+}
+
+// rt_hip_trace_closest: CScene::FirstInterPt_BSPTree / FirstInterPt for a list of rays
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(DevScene sc, const rt_hip_ray *rays, size_t n, rt_hip_hit *hits, Stats *gstats)
+{
+  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
+  int *stack = s_stack[threadIdx.x >> 6];
+  const size_t i = (size_t)xcd_remap(blockIdx.x, gridDim.x) * RT_BLOCK + threadIdx.x;
+  const bool active = i < n;
+  Stats st{};
+  V3 o = mk(0, 0, 0), d = mk(1, 0, 0);
+  if (active) { const rt_hip_ray q = rays[i]; o = mk(q.o[0], q.o[1], q.o[2]); d = unitize(mk(q.d[0], q.d[1], q.d[2])); }
+  RayState r; ray_setup(r, o, d, sc.coord_scale);
+  if (STATS && active) st.rays++;
+  traverse<false, STATS>(sc, r, active, false, mk(0, 0, 0), stack, st);
+  if (active) {
+    rt_hip_hit h; h.prim_id = r.best_id; h.reserved = 0; h.u = kInfty; h.v = kInfty;
+    h.t = (r.best_id >= 0) ? r.best_t : kInfty;
+    hits[i] = h;
+  }
+  if (STATS) stats_flush(gstats, st);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_occluded(DevScene sc, const rt_hip_ray *rays, const double *ref_pts, size_t n,
+                                                              uint8_t *occluded, Stats *gstats)
+{
+  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
+  int *stack = s_stack[threadIdx.x >> 6];
+  const size_t i = (size_t)xcd_remap(blockIdx.x, gridDim.x) * RT_BLOCK + threadIdx.x;
+  const bool active = i < n;
+  Stats st{};
+  V3 o = mk(0, 0, 0), d = mk(1, 0, 0), ref = mk(0, 0, 0);
+  if (active) {
+    const rt_hip_ray q = rays[i]; o = mk(q.o[0], q.o[1], q.o[2]); d = unitize(mk(q.d[0], q.d[1], q.d[2]));
+    if (ref_pts) ref = mk(ref_pts[3 * i], ref_pts[3 * i + 1], ref_pts[3 * i + 2]);
+  }
+  RayState r; ray_setup(r, o, d, sc.coord_scale);
+  if (ref_pts) r.best_t = fabs(dot(ref - o, d)) + 1e-6 * (1.0 + sc.coord_scale);
+  if (STATS && active) { st.rays++; st.shadow_rays++; }
+  bool occ = traverse<true, STATS>(sc, r, active, ref_pts != nullptr, ref, stack, st);
+  if (active) occluded[i] = occ ? 1 : 0;
+  if (STATS) stats_flush(gstats, st);
+}
+
+struct RenderArgs {
+  DevCamera cam;
+  double bg[3];
+  double weight_threshold;
+  uint64_t seed;
+  uint64_t pixel_first, pixel_count;
+  uint32_t v_lo, tiles_x, tiles_y;   // 8x8 tiling of the rows that hold the shard
+  uint32_t sample_first, n_samples;   // samples handled by this launch
+  double lens_radius; int focusing;
+};
+
+// level 0: camera / lens ray generation (Camera.h:65-67, 189-190) + closest hit, one 8x8 pixel tile per wave
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, RenderArgs A, PathNode *nodes, Stats *gstats)
+{
+  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
+  int *stack = s_stack[threadIdx.x >> 6];
+  const unsigned int wave = xcd_remap(blockIdx.x, gridDim.x) * RT_WAVES + (threadIdx.x >> 6);
+  const unsigned int lane = threadIdx.x & 63;
+  const unsigned int tiles = A.tiles_x * A.tiles_y;
+  const unsigned int s_local = wave / tiles, tile = wave % tiles;
+  const unsigned int h = (tile % A.tiles_x) * 8 + (lane & 7);
+  const unsigned int v = A.v_lo + (tile / A.tiles_x) * 8 + (lane >> 3);
+  const uint64_t p = (uint64_t)v * A.cam.W + h;
+  const bool active = (s_local < A.n_samples) && (h < (unsigned)A.cam.W) && (v < (unsigned)A.cam.H) &&
+                      (p >= A.pixel_first) && (p < A.pixel_first + A.pixel_count);
+  Stats st{};
+  const uint32_t sample = A.sample_first + s_local;
+  // curPt = startPt - left*(h/res) - up*(v/res), Camera.h:65
+  V3 cur = A.cam.start - A.cam.left * (double(h) / double(A.cam.res)) - A.cam.up * (double(v) / double(A.cam.res));
+  V3 o = A.cam.view_pt;
+  if (A.focusing) {   // Camera.h:189: lens point, draws in x,y,z order
+    double jx = ref_random(A.lens_radius, 1000, A.seed, (uint32_t)p, sample, 0, 0, 0, 0);
+    double jy = ref_random(A.lens_radius, 1000, A.seed, (uint32_t)p, sample, 0, 0, 0, 1);
+    double jz = ref_random(A.lens_radius, 1000, A.seed, (uint32_t)p, sample, 0, 0, 0, 2);
+    o = mk(o.x + jx, o.y + jy, o.z + jz);
+  }
+  V3 d = unitize(unitize(cur - o));     // Camera.h:67 + CRay ctor (Geometry.h:253-254)
+  RayState r; ray_setup(r, o, d, sc.coord_scale);
+  if (STATS && active) st.rays++;
+  traverse<false, STATS>(sc, r, active, false, mk(0, 0, 0), stack, st);
+  if (active) {
+    PathNode &nd = nodes[(uint64_t)s_local * A.pixel_count + (p - A.pixel_first)];
+    nd.o[0] = o.x; nd.o[1] = o.y; nd.o[2] = o.z; nd.d[0] = d.x; nd.d[1] = d.y; nd.d[2] = d.z;
+    nd.t = r.best_t; nd.weight = 1.0; nd.id = r.best_id;
+    nd.pixel = (uint32_t)p; nd.sample = sample; nd.path = 1;
+    nd.child_refr = -1; nd.child_refl = -1; nd.w_refr = 0; nd.w_refl = 0;
+  }
+  if (STATS) stats_flush(gstats, st);
+}
+
+// levels >= 1: closest hit for queued secondary rays
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n, Stats *gstats)
+{
+  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
+  int *stack = s_stack[threadIdx.x >> 6];
+  const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+  const bool active = i < n;
+  Stats st{};
+  V3 o = mk(0, 0, 0), d = mk(1, 0, 0);
+  if (active) { o = mk(nodes[i].o[0], nodes[i].o[1], nodes[i].o[2]); d = mk(nodes[i].d[0], nodes[i].d[1], nodes[i].d[2]); }
+  RayState r; ray_setup(r, o, d, sc.coord_scale);
+  if (STATS && active) st.rays++;
+  traverse<false, STATS>(sc, r, active, false, mk(0, 0, 0), stack, st);
+  if (active) { nodes[i].t = r.best_t; nodes[i].id = r.best_id; }
+  if (STATS) stats_flush(gstats, st);
+}
+
+// RayTracer (RayTracer.h:8-55) for one level of the ray tree: local illumination (with its shadow
+// queries) and generation of the refracted / reflected child rays into the next level's queue.
+template <bool STATS>
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, PathNode *nodes, unsigned int n, int depth_left,
+                                                     PathNode *next, unsigned int next_cap, RenderCounters *cnt, Stats *gstats)
+{
+  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
+  int *stack = s_stack[threadIdx.x >> 6];
+  const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+  const bool in_range = i < n;
+  Stats st{};
+  PathNode nd;
+  if (in_range) nd = nodes[i];
+  else { nd.id = -1; nd.t = kMiss; nd.weight = 0; nd.pixel = 0; nd.sample = 0; nd.path = 1; for (int k = 0; k < 3; k++) { nd.o[k] = 0; nd.d[k] = (k == 0); } }
+  const bool hit = in_range && nd.id >= 0;
+  const V3 o = mk(nd.o[0], nd.o[1], nd.o[2]), d = mk(nd.d[0], nd.d[1], nd.d[2]);
+  const V3 pt = hit ? (o + d * nd.t) : mk(0, 0, 0);     // ray.beginPt() + ray.direction() * t
+  RngKey key; key.seed = A.seed; key.pixel = nd.pixel; key.sample = nd.sample; key.path = nd.path;
+  V3 N;
+  Stats st0 = st;
+  Col c = local_illumination<STATS>(sc, o, d, nd.id, pt, hit, key, stack, st, N);
+  unsigned long long my_shadow = 0;
+  {
+    // shadow-ray census for rt_hip_last_ray_count: one query per light sample per hit node
+    if (hit) for (int li = 0; li < sc.n_lights; li++) { const DLight &L = sc.lights[li]; my_shadow += (L.type == 102) ? (unsigned long long)L.sample_num * L.sample_num : 1ull; }
+  }
+  (void)st0;
+  int child_refr = -1, child_refl = -1; double w_refr = 0, w_refl = 0;
+  bool want_refr = false, want_refl = false; V3 dir_refr = mk(0, 0, 0), dir_refl = mk(0, 0, 0);
+  if (!hit) { c = mkc(A.bg[0], A.bg[1], A.bg[2]); }
+  else if (depth_left > 1) {
+    const DMaterial M = sc.materials[sc.obj_mat[nd.id]];
+    double refrW = M.refrW, reflW = M.reflW;
+    if (!(M.reflW == 0 || M.refrW == 0)) {             // Fresnel, Object.h:130-131, 159-160
+      double R = fresnel_R(N, d, M.RI);
+      reflW = R; refrW = 1 - R;
+    }
+    bool total_reflect = false;
+    if (refrW != 0) {
+      V3 t = refract_dir(N, d, M.RI);
+      if (!is_infty_pt(t)) { w_refr = refrW; dir_refr = t; if (nd.weight * refrW < A.weight_threshold) child_refr = -2; else want_refr = true; }
+      else total_reflect = true;
+    }
+    if (reflW != 0) {
+      dir_refl = reflect_dir(N, d);
+      w_refl = total_reflect ? (reflW + refrW) : reflW;
+      if (nd.weight * w_refl < A.weight_threshold) child_refl = -2; else want_refl = true;
+    }
+  }
+  // wave-aggregated append of the child rays to the next level
+  const unsigned int lane = threadIdx.x & 63;
+  const unsigned long long m1 = __ballot(want_refr), m2 = __ballot(want_refl);
+  const unsigned int total = __popcll(m1) + __popcll(m2);
+  unsigned int base = 0;
+  if (total) {
+    if (lane == 0) base = atomicAdd(&cnt->queue_count, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+  }
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  if (want_refr) {
+    unsigned int k = base + __popcll(m1 & below);
+    if (k < next_cap) {
+      PathNode &q = next[k];
+      q.o[0] = pt.x; q.o[1] = pt.y; q.o[2] = pt.z; q.d[0] = dir_refr.x; q.d[1] = dir_refr.y; q.d[2] = dir_refr.z;
+      q.weight = nd.weight * w_refr; q.pixel = nd.pixel; q.sample = nd.sample; q.path = nd.path * 2;
+      q.id = -1; q.t = kMiss; q.child_refr = -1; q.child_refl = -1; q.w_refr = 0; q.w_refl = 0;
+      child_refr = (int)k;
+    }
+  }
+  if (want_refl) {
+    unsigned int k = base + __popcll(m1) + __popcll(m2 & below);
+    if (k < next_cap) {
+      PathNode &q = next[k];
+      q.o[0] = pt.x; q.o[1] = pt.y; q.o[2] = pt.z; q.d[0] = dir_refl.x; q.d[1] = dir_refl.y; q.d[2] = dir_refl.z;
+      q.weight = nd.weight * w_refl; q.pixel = nd.pixel; q.sample = nd.sample; q.path = nd.path * 2 + 1;
+      q.id = -1; q.t = kMiss; q.child_refr = -1; q.child_refl = -1; q.w_refr = 0; q.w_refl = 0;
+      child_refl = (int)k;
+    }
+  }
+  if (in_range) {
+    PathNode &w = nodes[i];
+    w.col[0] = c.r; w.col[1] = c.g; w.col[2] = c.b;
+    w.w_refr = w_refr; w.w_refl = w_refl; w.child_refr = child_refr; w.child_refl = child_refl;
+  }
+  // ray census (always on: it is what rt_hip_last_ray_count reports)
+  {
+    unsigned long long x = my_shadow;
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if (lane == 0 && x) atomicAdd(&cnt->shadow_rays, x);
+  }
+  if (STATS) stats_flush(gstats, st);
+}
+
+// bottom-up composition with the reference's clamped colour arithmetic (RayTracer.h:33, 45, 50)
+__global__ void __launch_bounds__(RT_BLOCK) k_combine(PathNode *nodes, unsigned int n, const PathNode *next, RenderArgs A)
+{
+  const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  PathNode &w = nodes[i];
+  Col c = mkc(w.col[0], w.col[1], w.col[2]);
+  const Col bg = mkc(A.bg[0], A.bg[1], A.bg[2]);
+  if (w.child_refr >= 0) { const PathNode &q = next[w.child_refr]; c = cadd(c, cmul(mkc(q.col[0], q.col[1], q.col[2]), w.w_refr)); }
+  else if (w.child_refr == -2) c = cadd(c, cmul(bg, w.w_refr));
+  if (w.child_refl >= 0) { const PathNode &q = next[w.child_refl]; c = cadd(c, cmul(mkc(q.col[0], q.col[1], q.col[2]), w.w_refl)); }
+  else if (w.child_refl == -2) c = cadd(c, cmul(bg, w.w_refl));
+  w.col[0] = c.r; w.col[1] = c.g; w.col[2] = c.b;
+}
+
+// Camera.h:69 up to the uchar store / Camera.h:191 accumulation over the samples of this launch
+__global__ void __launch_bounds__(RT_BLOCK) k_resolve(const PathNode *nodes, RenderArgs A, double spp, int accumulate,
+                                                      double *rgb, int32_t *prim_id)
+{
+  const uint64_t q = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+  if (q >= A.pixel_count) return;
+  if (!A.focusing) {
+    const PathNode &w = nodes[q];
+    rgb[3 * q] = w.col[0]; rgb[3 * q + 1] = w.col[1]; rgb[3 * q + 2] = w.col[2];
+    if (prim_id) prim_id[q] = w.id;
+    return;
+  }
+  double r = accumulate ? rgb[3 * q] : 0.0, g = accumulate ? rgb[3 * q + 1] : 0.0, b = accumulate ? rgb[3 * q + 2] : 0.0;
+  for (uint32_t s = 0; s < A.n_samples; s++) {
+    const PathNode &w = nodes[(uint64_t)s * A.pixel_count + q];
+    Col c = cdiv(mkc(w.col[0], w.col[1], w.col[2]), spp);   // RayTracer(...) / sampleTimes
+    r += c.r; g += c.g; b += c.b;
+  }
+  rgb[3 * q] = r; rgb[3 * q + 1] = g; rgb[3 * q + 2] = b;
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" int rt_hip_device_count(int *n)
+{
+  if (!n) return fail(RT_HIP_EINVAL, "n is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *n = 0; return fail(RT_HIP_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  *n = c;
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_context_create(int device_id, rt_hip_ctx **out)
+{
+  if (!out) return fail(RT_HIP_EINVAL, "out is NULL");
+  *out = nullptr;
+  int c = 0;
+  HIP_TRY(hipGetDeviceCount(&c));
+  if (c <= 0) return fail(RT_HIP_EHIP, "no HIP device: this library has no CPU fallback");
+  if (device_id < 0 || device_id >= c) return fail(RT_HIP_EINVAL, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  rt_hip_ctx *ctx = new rt_hip_ctx();
+  ctx->device = device_id;
+  hipError_t e = hipMalloc((void **)&ctx->d_stats, sizeof(Stats));
+  if (e != hipSuccess) { delete ctx; return fail(RT_HIP_ENOMEM, std::string("hipMalloc stats: ") + hipGetErrorString(e)); }
+  e = hipMemset(ctx->d_stats, 0, sizeof(Stats));
+  if (e != hipSuccess) { (void)hipFree(ctx->d_stats); delete ctx; return fail(RT_HIP_EHIP, std::string("hipMemset: ") + hipGetErrorString(e)); }
+  *out = ctx;
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_context_destroy(rt_hip_ctx *ctx)
+{
+  if (!ctx) return RT_HIP_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+  delete ctx;
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_get_stats(rt_hip_ctx *ctx, rt_hip_stats *out, int reset)
+{
+  if (!ctx || !out) return fail(RT_HIP_EINVAL, "NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  Stats s;
+  HIP_TRY(hipMemcpy(&s, ctx->d_stats, sizeof s, hipMemcpyDeviceToHost));
+  out->rays = s.rays; out->shadow_rays = s.shadow_rays; out->node_visits = s.node_visits; out->prim_tests = s.prim_tests;
+  out->exact_tests = s.exact_tests; out->wave_node_visits = s.wave_nodes; out->wave_prim_tests = s.wave_prims; out->reserved = 0;
+  if (reset) HIP_TRY(hipMemset(ctx->d_stats, 0, sizeof(Stats)));
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
+{
+  if (!s) return RT_HIP_OK;
+  if (s->ctx) (void)hipSetDevice(s->ctx->device);
+  for (void *p : s->allocs) (void)hipFree(p);
+  for (auto &b : s->levels) b.release();
+  s->counter.release(); s->staging.release();
+  delete s;
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, uint32_t leaf_refine, rt_hip_scene **out)
+{
+  if (!ctx || !d || !out) return fail(RT_HIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (d->struct_size != sizeof(rt_hip_scene_desc)) return fail(RT_HIP_EINVAL, "rt_hip_scene_desc.struct_size mismatch");
+  if (d->n_objects == 0) return fail(RT_HIP_EINVAL, "scene has no objects");
+  if (!d->obj_type || !d->obj_index || !d->obj_material || !d->obj_colour) return fail(RT_HIP_EINVAL, "object arrays missing");
+  if ((d->n_triangles && !d->triangles) || (d->n_planes && !d->planes) || (d->n_spheres && !d->spheres) ||
+      (d->n_circles && !d->circles) || (d->n_lights && !d->lights) || !d->materials || d->n_materials == 0)
+    return fail(RT_HIP_EINVAL, "type arrays missing");
+  if (d->n_lights > 16) return fail(RT_HIP_EUNSUPPORTED, "more than 16 lights");
+  for (uint32_t i = 0; i < d->n_objects; i++) {
+    uint32_t k = d->obj_index[i], lim = 0;
+    switch (d->obj_type[i]) {
+      case RT_HIP_TRIANGLE: lim = d->n_triangles; break;
+      case RT_HIP_INFTY_PLANE: lim = d->n_planes; break;
+      case RT_HIP_SPHERE: lim = d->n_spheres; break;
+      case RT_HIP_CIRCLE: lim = d->n_circles; break;
+      default: return fail(RT_HIP_EUNSUPPORTED, "object type " + std::to_string((int)d->obj_type[i]) + " is not supported");
+    }
+    if (k >= lim) return fail(RT_HIP_EINVAL, "obj_index out of range at object " + std::to_string(i));
+    if (d->obj_material[i] >= d->n_materials) return fail(RT_HIP_EINVAL, "obj_material out of range");
+  }
+  for (uint32_t i = 0; i < d->n_lights; i++) {
+    const rt_hip_light &L = d->lights[i];
+    if (L.type != RT_HIP_POINT_LIGHT && L.type != RT_HIP_PARALLEL_LIGHT && L.type != RT_HIP_AREA_LIGHT)
+      return fail(RT_HIP_EINVAL, "bad light type");
+    if (L.type == RT_HIP_AREA_LIGHT && (L.sample_num < 1 || L.sample_num > 127)) return fail(RT_HIP_EINVAL, "area light sample_num out of range [1,127]");
+  }
+  if (d->n_nodes && (!d->nodes || (d->n_refs && !d->refs) || (d->n_root_objects && !d->root_objects)))
+    return fail(RT_HIP_EINVAL, "tree arrays missing");
+  for (uint32_t i = 0; i < d->n_root_objects; i++)
+    if (d->root_objects[i] >= d->n_objects) return fail(RT_HIP_EINVAL, "root_objects out of range");
+
+  HIP_TRY(hipSetDevice(ctx->device));
+  rt_hip_scene *s = new rt_hip_scene();
+  s->ctx = ctx;
+  Builder B; B.d = d; B.leaf_refine = leaf_refine;
+  // triangles: m_norm = ((v1 - v0) ^ (v2 - v0)).Unitize(), Object.h:365
+  B.tri_exact.resize(d->n_triangles);
+  std::vector<TriShade> tri_shade(d->n_triangles);
+  for (uint32_t k = 0; k < d->n_triangles; k++) {
+    const rt_hip_triangle &t = d->triangles[k];
+    V3 v0 = mk(t.v[0][0], t.v[0][1], t.v[0][2]), v1 = mk(t.v[1][0], t.v[1][1], t.v[1][2]), v2 = mk(t.v[2][0], t.v[2][1], t.v[2][2]);
+    V3 n = unitize(cross(v1 - v0, v2 - v0));
+    TriExact &T = B.tri_exact[k];
+    T.v0[0] = v0.x; T.v0[1] = v0.y; T.v0[2] = v0.z; T.v1[0] = v1.x; T.v1[1] = v1.y; T.v1[2] = v1.z;
+    T.v2[0] = v2.x; T.v2[1] = v2.y; T.v2[2] = v2.z; T.nrm[0] = n.x; T.nrm[1] = n.y; T.nrm[2] = n.z;
+    TriShade &S = tri_shade[k];
+    std::memcpy(S.vn, t.vn, sizeof S.vn); S.has_vn = t.has_vn; S.pad = 0;
+  }
+  B.object_boxes();
+  double cs = 0;
+  std::vector<int32_t> root_objs;
+  if (d->n_nodes) {
+    int root = B.walk(0, 0);
+    if (!B.err.empty()) { rt_hip_scene_destroy(s); return fail(RT_HIP_EINVAL, "tree: " + B.err); }
+    // the device walk starts at node 0: move the root there
+    if (root >= 0) {
+      std::vector<DNode> re; re.reserve(B.nodes.size());
+      // reverse order puts the root first; children indices are remapped accordingly
+      const int N = (int)B.nodes.size();
+      // root is the last node emitted unless pruning returned a child; make a generic remap via BFS
+      std::vector<int> order, map(N, -1);
+      order.push_back(root); map[root] = 0;
+      for (size_t q = 0; q < order.size(); q++) {
+        const DNode &nd = B.nodes[order[q]];
+        if (nd.axis >= 0) { map[nd.a] = (int)order.size(); order.push_back(nd.a); map[nd.b] = (int)order.size(); order.push_back(nd.b); }
+      }
+      for (int oi : order) { DNode nd = B.nodes[oi]; if (nd.axis >= 0) { nd.a = map[nd.a]; nd.b = map[nd.b]; } re.push_back(nd); }
+      B.nodes.swap(re);
+      for (int a = 0; a < 3; a++) cs = std::max(cs, std::max(std::fabs(B.nodes[0].bmin[a]), std::fabs(B.nodes[0].bmax[a])));
+    } else B.nodes.clear();
+    if (B.nodes.empty()) {
+      // a tree without finite content: keep one empty leaf so that "has tree" semantics (Scene.h:87) hold
+      DNode nd; std::memset(&nd, 0, sizeof nd); nd.axis = -1;
+      for (int a = 0; a < 3; a++) { nd.bmin[a] = 1e300; nd.bmax[a] = -1e300; }
+      B.nodes.push_back(nd);
+    }
+    // root->objects: when the reference root was never split it holds ALL objects (BSPTree.h:60); finite
+    // ones are already in the root leaf, so only the infinite ones are kept for the per-ray list
+    for (uint32_t i = 0; i < d->n_root_objects; i++) if (!B.finite[d->root_objects[i]]) root_objs.push_back((int32_t)d->root_objects[i]);
+  } else {
+    for (uint32_t i = 0; i < d->n_objects; i++) if (B.finite[i]) for (int a = 0; a < 3; a++)
+      cs = std::max(cs, std::max(std::fabs(B.aabb[i].mn[a]), std::fabs(B.aabb[i].mx[a])));
+  }
+  std::vector<DPlane> planes(d->n_planes); std::vector<DSphere> spheres(d->n_spheres); std::vector<DCircle> circles(d->n_circles);
+  for (uint32_t k = 0; k < d->n_planes; k++) { std::memcpy(planes[k].p0, d->planes[k].p0, 24); std::memcpy(planes[k].n, d->planes[k].n, 24); }
+  for (uint32_t k = 0; k < d->n_spheres; k++) { std::memcpy(spheres[k].c, d->spheres[k].c, 24); spheres[k].r = d->spheres[k].r; }
+  for (uint32_t k = 0; k < d->n_circles; k++) { std::memcpy(circles[k].p0, d->circles[k].p0, 24); std::memcpy(circles[k].n, d->circles[k].n, 24); circles[k].r = d->circles[k].r; }
+  std::vector<DMaterial> mats(d->n_materials);
+  for (uint32_t k = 0; k < d->n_materials; k++) std::memcpy(&mats[k], &d->materials[k], sizeof(DMaterial));
+  std::vector<DLight> lights(d->n_lights);
+  for (uint32_t k = 0; k < d->n_lights; k++) {
+    const rt_hip_light &L = d->lights[k]; DLight &o = lights[k];
+    o.type = L.type; o.sample_num = L.sample_num; std::memcpy(o.p, L.pos_or_dir, 24); o.lum = L.luminosity; o.len = L.len;
+    o.lum_per_sample = (L.type == RT_HIP_AREA_LIGHT) ? L.luminosity / (L.sample_num * L.sample_num) : 0.0;   // Light.h:107
+  }
+  std::vector<uint8_t> types(d->obj_type, d->obj_type + d->n_objects);
+  std::vector<uint32_t> index(d->obj_index, d->obj_index + d->n_objects), omat(d->obj_material, d->obj_material + d->n_objects);
+  std::vector<double> colour(d->obj_colour, d->obj_colour + 3 * (size_t)d->n_objects);
+
+  DevScene &D = s->dev;
+  int rc = RT_HIP_OK;
+  auto up = [&](int r) { if (rc == RT_HIP_OK) rc = r; };
+  up(upload(s, B.nodes, &D.nodes)); up(upload(s, B.cull, &D.cull)); up(upload(s, B.leaf_other, &D.leaf_other));
+  up(upload(s, root_objs, &D.root_objs)); up(upload(s, B.tri_exact, &D.tri_exact)); up(upload(s, tri_shade, &D.tri_shade));
+  up(upload(s, planes, &D.planes)); up(upload(s, spheres, &D.spheres)); up(upload(s, circles, &D.circles));
+  up(upload(s, types, &D.obj_type)); up(upload(s, index, &D.obj_index)); up(upload(s, omat, &D.obj_mat));
+  up(upload(s, colour, &D.obj_colour)); up(upload(s, mats, &D.materials)); up(upload(s, lights, &D.lights));
+  if (rc != RT_HIP_OK) { std::string m = g_err; rt_hip_scene_destroy(s); return fail(rc, m); }
+  D.n_nodes = (int32_t)B.nodes.size(); if (!d->n_nodes) D.n_nodes = 0;
+  D.n_root_objs = (int32_t)root_objs.size(); D.n_objects = (int32_t)d->n_objects; D.n_lights = (int32_t)d->n_lights;
+  D.ambient = d->ambient; D.coord_scale = cs;
+  s->n_nodes = (uint32_t)B.nodes.size(); s->n_leaves = B.n_leaves; s->n_cull = (uint32_t)B.cull.size(); s->max_depth = B.max_depth;
+  *out = s;
+  return RT_HIP_OK;
+}
+
+static inline unsigned int blocks_for(size_t n) { return (unsigned int)((n + RT_BLOCK - 1) / RT_BLOCK); }
+
+extern "C" int rt_hip_trace_closest_dev(rt_hip_scene *s, const rt_hip_ray *d_rays, size_t n, int use_tree, int record,
+                                         rt_hip_hit *d_hits, uint32_t collect_stats, void *stream)
+{
+  (void)record;   // identical for sphere / triangle / circle / plane (Object.h:238, 333, 659, 692)
+  if (!s || (n && (!d_rays || !d_hits))) return fail(RT_HIP_EINVAL, "NULL argument");
+  if (n == 0) return RT_HIP_OK;
+  if (n > 0xFFFFFFFFull * 64) return fail(RT_HIP_EINVAL, "too many rays");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  DevScene sc = s->dev; if (!use_tree) sc.n_nodes = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (collect_stats) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, sc, d_rays, n, d_hits, s->ctx->d_stats);
+  else hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, sc, d_rays, n, d_hits, (Stats *)nullptr);
+  HIP_TRY(hipGetLastError());
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_trace_closest(rt_hip_scene *s, const rt_hip_ray *rays, size_t n, int use_tree, int record, rt_hip_hit *hits)
+{
+  if (!s || (n && (!rays || !hits))) return fail(RT_HIP_EINVAL, "NULL argument");
+  if (n == 0) return RT_HIP_OK;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  size_t rb = n * sizeof(rt_hip_ray), hb = n * sizeof(rt_hip_hit);
+  int rc = s->staging.ensure(rb + hb); if (rc) return rc;
+  rt_hip_ray *dr = (rt_hip_ray *)s->staging.p; rt_hip_hit *dh = (rt_hip_hit *)((char *)s->staging.p + rb);
+  HIP_TRY(hipMemcpy(dr, rays, rb, hipMemcpyHostToDevice));
+  rc = rt_hip_trace_closest_dev(s, dr, n, use_tree, record, dh, 0, nullptr); if (rc) return rc;
+  HIP_TRY(hipMemcpy(hits, dh, hb, hipMemcpyDeviceToHost));
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_trace_occluded(rt_hip_scene *s, const rt_hip_ray *rays, const double *ref_pts, size_t n, int use_tree, uint8_t *occluded)
+{
+  if (!s || (n && (!rays || !occluded))) return fail(RT_HIP_EINVAL, "NULL argument");
+  if (n == 0) return RT_HIP_OK;
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  size_t rb = n * sizeof(rt_hip_ray), pb = ref_pts ? n * 24 : 0, ob = (n + 15) & ~(size_t)15;
+  int rc = s->staging.ensure(rb + pb + ob); if (rc) return rc;
+  char *base = (char *)s->staging.p;
+  HIP_TRY(hipMemcpy(base, rays, rb, hipMemcpyHostToDevice));
+  if (ref_pts) HIP_TRY(hipMemcpy(base + rb, ref_pts, pb, hipMemcpyHostToDevice));
+  DevScene sc = s->dev; if (!use_tree) sc.n_nodes = 0;
+  hipLaunchKernelGGL(k_trace_occluded<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, nullptr, sc, (const rt_hip_ray *)base,
+                     ref_pts ? (const double *)(base + rb) : (const double *)nullptr, n, (uint8_t *)(base + rb + pb), (Stats *)nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(occluded, base + rb + pb, n, hipMemcpyDeviceToHost));
+  return RT_HIP_OK;
+}
+
+// CCamera constructor + the loop-invariant part of Render_RayTracer (Camera.h:17-28, 55-57)
+static int camera_setup(const rt_hip_camera *c, DevCamera *k)
+{
+  if (!c) return fail(RT_HIP_EINVAL, "camera is NULL");
+  if (c->resolution <= 0) return fail(RT_HIP_EINVAL, "camera resolution must be positive");
+  V3 v_eye = mk(c->eye_dir[0], c->eye_dir[1], c->eye_dir[2]), v_left = mk(c->left[0], c->left[1], c->left[2]);
+  V3 view = mk(c->view_pt[0], c->view_pt[1], c->view_pt[2]);
+  V3 eye = unitize(v_eye);
+  V3 up = unitize(cross(v_left, v_eye));
+  V3 left = unitize(cross(up, eye));
+  V3 center = view + eye * c->dist_of_plane;
+  k->view_pt = view; k->left = left; k->up = up;
+  k->res = c->resolution; k->depth = c->depth;
+  k->W = (int)(c->hor_range * c->resolution); k->H = (int)(c->ver_range * c->resolution);
+  k->start = center + left * (c->hor_range / 2) + up * (c->ver_range / 2);
+  if (k->W <= 0 || k->H <= 0) return fail(RT_HIP_EINVAL, "empty image");
+  if ((uint64_t)k->W * k->H > 0xFFFFFFFFull) return fail(RT_HIP_EINVAL, "image too large");
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_camera_size(const rt_hip_camera *cam, int *w, int *h)
+{
+  DevCamera k; int rc = camera_setup(cam, &k); if (rc) return rc;
+  if (w) *w = k.W; if (h) *h = k.H;
+  return RT_HIP_OK;
+}
+
+// the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
+static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st)
+{
+  const uint64_t n0 = A.pixel_count * A.n_samples;
+  if (n0 == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
+  int rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
+  rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
+  RenderCounters *cnt = (RenderCounters *)s->counter.p;
+  Stats *gs = stats ? s->ctx->d_stats : nullptr;
+  const unsigned int waves = A.tiles_x * A.tiles_y * A.n_samples;
+  const unsigned int pblocks = (waves + RT_WAVES - 1) / RT_WAVES;
+  PathNode *L0 = (PathNode *)s->levels[0].p;
+  if (stats) hipLaunchKernelGGL(k_primary<true>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, gs);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, gs);
+  HIP_TRY(hipGetLastError());
+  unsigned int n_level[rt_hip_scene::kMaxLevels] = {0};
+  n_level[0] = (unsigned int)n0;
+  int depth = A.cam.depth < 1 ? 1 : A.cam.depth;
+  if (depth > rt_hip_scene::kMaxLevels) return fail(RT_HIP_EUNSUPPORTED, "camera depth > 16");
+  int last = 0;
+  for (int lv = 0; lv < depth; lv++) {
+    const unsigned int n = n_level[lv];
+    if (n == 0) break;
+    last = lv;
+    const int depth_left = depth - lv;
+    unsigned int next_cap = 0; PathNode *next = nullptr;
+    if (depth_left > 1) {
+      uint64_t cap = 2ull * n;
+      if (cap > 0x7FFFFFFFull) return fail(RT_HIP_ENOMEM, "ray tree level too large");
+      rc = s->levels[lv + 1].ensure(cap * sizeof(PathNode)); if (rc) return rc;
+      next = (PathNode *)s->levels[lv + 1].p; next_cap = (unsigned int)cap;
+    }
+    HIP_TRY(hipMemsetAsync(&cnt->queue_count, 0, sizeof(unsigned int), st));
+    PathNode *cur = (PathNode *)s->levels[lv].p;
+    if (lv > 0) {
+      if (stats) hipLaunchKernelGGL(k_trace_nodes<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, cur, n, gs);
+      else hipLaunchKernelGGL(k_trace_nodes<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, cur, n, gs);
+    }
+    if (stats) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, next, next_cap, cnt, gs);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, next, next_cap, cnt, gs);
+    HIP_TRY(hipGetLastError());
+    if (depth_left > 1) {
+      unsigned int qn = 0;
+      HIP_TRY(hipMemcpyAsync(&qn, &cnt->queue_count, sizeof qn, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      n_level[lv + 1] = std::min(qn, next_cap);
+    }
+  }
+  for (int lv = last - 1; lv >= 0; lv--) {
+    hipLaunchKernelGGL(k_combine, dim3(blocks_for(n_level[lv])), dim3(RT_BLOCK), 0, st, (PathNode *)s->levels[lv].p, n_level[lv],
+                       (const PathNode *)s->levels[lv + 1].p, A);
+    HIP_TRY(hipGetLastError());
+  }
+  uint64_t rays = 0; for (int lv = 0; lv <= last; lv++) rays += n_level[lv];
+  s->last_rays += rays;
+  return RT_HIP_OK;
+}
+
+static int fill_args(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, RenderArgs *A)
+{
+  if (!s || !P) return fail(RT_HIP_EINVAL, "NULL argument");
+  if (P->struct_size != sizeof(rt_hip_params)) return fail(RT_HIP_EINVAL, "rt_hip_params.struct_size mismatch");
+  int rc = camera_setup(cam, &A->cam); if (rc) return rc;
+  const uint64_t total = (uint64_t)A->cam.W * A->cam.H;
+  A->pixel_first = P->pixel_count ? P->pixel_first : 0;
+  A->pixel_count = P->pixel_count ? P->pixel_count : total;
+  if (A->pixel_first >= total || A->pixel_count > total - A->pixel_first) return fail(RT_HIP_EINVAL, "pixel shard outside the image");
+  for (int k = 0; k < 3; k++) A->bg[k] = P->background[k];
+  A->weight_threshold = (P->weight_threshold > 0) ? P->weight_threshold : 0.1;   // RayTracer.h:7
+  A->seed = P->seed;
+  A->v_lo = (uint32_t)(A->pixel_first / A->cam.W);
+  const uint32_t v_hi = (uint32_t)((A->pixel_first + A->pixel_count - 1) / A->cam.W);
+  A->tiles_x = (uint32_t)(A->cam.W + 7) / 8; A->tiles_y = (v_hi - A->v_lo + 8) / 8;
+  A->sample_first = 0; A->n_samples = 1; A->lens_radius = 0; A->focusing = 0;
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *d_rgb,
+                                          int32_t *d_prim_id, void *stream)
+{
+  RenderArgs A; int rc = fill_args(s, cam, P, &A); if (rc) return rc;
+  if (!d_rgb) return fail(RT_HIP_EINVAL, "rgb is NULL");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
+  s->last_rays = 0; s->last_shadow = 0;
+  rc = run_levels(s, A, P->collect_stats != 0, st); if (rc) return rc;
+  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, 1.0, 0, d_rgb, d_prim_id);
+  HIP_TRY(hipGetLastError());
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_render_focusing_dev(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *d_rgb, void *stream)
+{
+  RenderArgs A; int rc = fill_args(s, cam, P, &A); if (rc) return rc;
+  if (!d_rgb) return fail(RT_HIP_EINVAL, "rgb is NULL");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t spp = P->spp ? P->spp : 100;       // Camera.h:171
+  uint32_t s_first = P->sample_count ? P->sample_first : 0, s_count = P->sample_count ? P->sample_count : spp;
+  if (s_first >= spp || s_count > spp - s_first) return fail(RT_HIP_EINVAL, "sample shard outside [0, spp)");
+  A.focusing = 1; A.lens_radius = P->lens_radius;
+  rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
+  s->last_rays = 0; s->last_shadow = 0;
+  // batch the samples so that one level-0 array stays near 1 GiB
+  uint64_t per = (1ull << 30) / (A.pixel_count * sizeof(PathNode));
+  uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per, 64));
+  for (uint32_t done = 0; done < s_count; done += batch) {
+    A.sample_first = s_first + done; A.n_samples = std::min(batch, s_count - done);
+    rc = run_levels(s, A, P->collect_stats != 0, st); if (rc) return rc;
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, (double)spp,
+                       done ? 1 : 0, d_rgb, (int32_t *)nullptr);
+    HIP_TRY(hipGetLastError());
+  }
+  return RT_HIP_OK;
+}
+
+static int render_host(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *rgb, int32_t *prim_id, bool focusing)
+{
+  RenderArgs A; int rc = fill_args(s, cam, P, &A); if (rc) return rc;
+  if (!rgb) return fail(RT_HIP_EINVAL, "rgb is NULL");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  size_t cb = A.pixel_count * 24, ib = A.pixel_count * 4;
+  rc = s->staging.ensure(cb + ib); if (rc) return rc;
+  double *d_rgb = (double *)s->staging.p; int32_t *d_id = (int32_t *)((char *)s->staging.p + cb);
+  rc = focusing ? rt_hip_render_focusing_dev(s, cam, P, d_rgb, nullptr) : rt_hip_render_whitted_dev(s, cam, P, d_rgb, prim_id ? d_id : nullptr, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(rgb, d_rgb, cb, hipMemcpyDeviceToHost));
+  if (prim_id && !focusing) HIP_TRY(hipMemcpy(prim_id, d_id, ib, hipMemcpyDeviceToHost));
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_render_whitted(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *rgb, int32_t *prim_id)
+{ return render_host(s, cam, P, rgb, prim_id, false); }
+
+extern "C" int rt_hip_render_focusing(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *rgb)
+{ return render_host(s, cam, P, rgb, nullptr, true); }
+
+extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *shadow_rays)
+{
+  if (!s) return fail(RT_HIP_EINVAL, "NULL argument");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  RenderCounters c{};
+  if (s->counter.p) HIP_TRY(hipMemcpy(&c, s->counter.p, sizeof c, hipMemcpyDeviceToHost));
+  if (rays) *rays = s->last_rays + c.shadow_rays;
+  if (shadow_rays) *shadow_rays = c.shadow_rays;
+  return RT_HIP_OK;
+}

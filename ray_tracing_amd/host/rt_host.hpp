@@ -1,0 +1,391 @@
+// rt_host.hpp -- C++ host layer that keeps the reference renderer's scene-side interface
+// (CScene / CCamera / CMaterial of Scene.h, Camera.h, Material.h) and executes the hot path through
+// the rt_hip_* C ABI (include/rt_hip.h).  A layout written against the reference's Layout.h reads
+// the same here:
+//
+//     rt::host::Scene scene(0.5);
+//     scene.AddInftyPlane({0,0,0}, {0,0,1}, Material(_PLASTIC_), Colour(255,255,255));
+//     scene.ReadObjFile_Triangle("Icosahedron_Triangle.obj", {0,-1,0}, 0.0015, Material(_PLASTIC_), Colour(241,46,24));
+//     scene.ConstructBSPTree();
+//     scene.AddAreaLight({-10,20,20}, 1, 10, 10);
+//     rt::host::Camera camera({-10,0,1.5}, {1,0,0}, {0,-1,0}, 10, 6, 6, 200, 1);
+//     camera.Render_RayTracer(scene, Colour(200,200,200));      // -> camera.image()
+//
+// What stays on the host (as in the reference): OBJ parsing (Parser.h), materials, lights, the
+// BSP-tree BUILD (BSPTree.h:58-109).  What moves behind the ABI: every ray-scene query and all
+// shading.  The OpenMP pixel loops of Camera.h disappear because rt_hip_render_* is a batch call.
+//
+// Build with -ffp-contract=off so that host-side derived values (unitized normals, boxes) round as
+// in the reference.  Paths cited are relative to /root/reference/RayTracing/.
+#pragma once
+#include "../../include/rt_hip.h"
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+// material preset names, Material.h:4-10
+#define _MIRROR_ 200
+#define _GLASS_ 201
+#define _ICE_ 202
+#define _METAL_ 203
+#define _PORCELAIN_ 204
+#define _RUBBER_ 205
+#define _PLASTIC_ 206
+
+namespace rt { namespace host {
+
+constexpr double eps = 1e-8;     // Geometry.h:12
+constexpr double infty = 1e+8;   // Geometry.h:48
+
+struct Point3D {                 // CPoint3D, Geometry.h:16-46
+  double x = 0, y = 0, z = 0;
+  Point3D() {}
+  Point3D(double a, double b, double c) : x(a), y(b), z(c) {}
+  Point3D operator+(const Point3D &p) const { return Point3D(x + p.x, y + p.y, z + p.z); }
+  Point3D operator-(const Point3D &p) const { return Point3D(x - p.x, y - p.y, z - p.z); }
+  Point3D operator*(double l) const { return Point3D(x * l, y * l, z * l); }
+  Point3D operator^(const Point3D &p) const { return Point3D(y * p.z - z * p.y, z * p.x - x * p.z, x * p.y - y * p.x); }
+  bool operator==(const Point3D &p) const { return std::fabs(x - p.x) < eps && std::fabs(y - p.y) < eps && std::fabs(z - p.z) < eps; }
+  double Len() const { return std::sqrt(x * x + y * y + z * z); }
+  Point3D Unitize() const                                   // Geometry.h:113-119
+  {
+    if (*this == Point3D(0, 0, 0) || *this == Point3D(infty, infty, infty)) return Point3D(infty, infty, infty);
+    double l = Len();
+    return Point3D(x / l, y / l, z / l);
+  }
+};
+
+struct Colour { double R = 0, G = 0, B = 0; Colour() {} Colour(double r, double g, double b) : R(r), G(g), B(b) {} };  // Colour.h:7-24
+
+struct Material {                // CMaterial, Material.h:13-124
+  rt_hip_material m{};
+  Material(double reflW, double refrW, double RI) { m.reflW = reflW; m.refrW = refrW; m.RI = RI; }
+  explicit Material(int name)
+  {
+    auto set = [&](double a, double b, double c, double d, double e, double f, double g, double h) {
+      m.reflW = a; m.refrW = b; m.RI = c; m.diff = d; m.spec = e; m.shiness = f; m.emissive = g; m.ambient = h; };
+    switch (name) {
+      case _MIRROR_: set(1, 0, 0, 0, 1, 2, 0, 0); break;
+      case _GLASS_: set(0.05, 0.95, 1.52, 0, 0.05, 20, 0, 0); break;
+      case _ICE_: set(0.05, 0.95, 1.31, 0, 0.05, 20, 0, 1); break;
+      case _METAL_: set(0.7, 0, 0, 0.2, 0.8, 20, 0, 1); break;
+      case _PORCELAIN_: set(0.1, 0, 0, 1, 0.1, 2, 0, 1); break;
+      case _RUBBER_: set(0, 0, 0, 0.3, 0.4, 1, 0, 1); break;
+      case _PLASTIC_: set(0, 0, 0, 0.6, 0.0, 1, 0, 1); break;
+      default: throw std::invalid_argument("unknown material preset");
+    }
+  }
+};
+
+struct Error : std::runtime_error { int code; Error(int c, const std::string &w) : std::runtime_error(w), code(c) {} };
+inline void check(int rc, const char *what) { if (rc != RT_HIP_OK) throw Error(rc, std::string(what) + ": " + rt_hip_last_error()); }
+
+class Context {                  // one GPU
+ public:
+  explicit Context(int device = 0) { check(rt_hip_context_create(device, &ctx_), "rt_hip_context_create"); }
+  ~Context() { rt_hip_context_destroy(ctx_); }
+  Context(const Context &) = delete; Context &operator=(const Context &) = delete;
+  rt_hip_ctx *get() const { return ctx_; }
+ private:
+  rt_hip_ctx *ctx_ = nullptr;
+};
+
+// CObjMesh, Parser.h:9-82 (token loop of LoadObjFile restated; only v / vt / vn / f are read)
+struct ObjMesh {
+  struct Tuple { int pointIndex, texCoordsIndex, normIndex; };
+  std::vector<Point3D> points, normals;
+  std::vector<std::array<double, 2>> texCoords;
+  std::vector<std::vector<Tuple>> faces;
+  explicit ObjMesh(const std::string &filename)
+  {
+    std::fstream in; in.open(filename, std::ios_base::in);
+    if (!in.is_open()) throw std::runtime_error("cannot open " + filename);
+    std::string flag;
+    for (; in.good();) {
+      in >> flag;                                      // a failed read leaves `flag` as it was (Parser.h:42)
+      if (flag == "v") { double x = 0, y = 0, z = 0; in >> x >> y >> z; points.push_back(Point3D(x, y, z)); }
+      else if (flag == "vt") { double u = 0, v = 0; in >> u >> v; texCoords.push_back({u, v}); }
+      else if (flag == "vn") { double x = 0, y = 0, z = 0; in >> x >> y >> z; normals.push_back(Point3D(x, y, z)); }
+      else if (flag == "f") {
+        char tuples[2048] = {};
+        in.getline(tuples, 2048, '\n');
+        std::vector<Tuple> face;
+        int a = 0, b = 0, c = 0, read = 0;
+        for (int i = 0; std::sscanf(&tuples[i], "%i/%i/%i%n", &a, &b, &c, &read) == 3;) {   // Parser.h:68
+          i += read; face.push_back({a - 1, b - 1, c - 1});
+        }
+        if (!face.empty()) faces.push_back(face);
+      }
+    }
+  }
+};
+
+class Scene {                    // CScene, Scene.h:12-60
+ public:
+  explicit Scene(double ambient = 0) : ambient_(ambient) {}
+  ~Scene() { rt_hip_scene_destroy(dev_); }
+  Scene(const Scene &) = delete; Scene &operator=(const Scene &) = delete;
+
+  // ---- objects (ids = insertion order = index in CScene::objects) ----
+  int AddSphere(Point3D c, double r, const Material &m, Colour col)               // Scene.h:124
+  { rt_hip_sphere s{{c.x, c.y, c.z}, r}; spheres_.push_back(s); return add(RT_HIP_SPHERE, (uint32_t)spheres_.size() - 1, m, col); }
+  int AddInftyPlane(Point3D p0, Point3D n, const Material &m, Colour col)         // Scene.h:130, Object.h:685-689
+  { Point3D u = n.Unitize(); rt_hip_plane p{{p0.x, p0.y, p0.z}, {u.x, u.y, u.z}}; planes_.push_back(p); return add(RT_HIP_INFTY_PLANE, (uint32_t)planes_.size() - 1, m, col); }
+  int AddCircle(Point3D p0, Point3D n, double r, const Material &m, Colour col)   // Object.h:651-656
+  { Point3D u = n.Unitize(); rt_hip_circle c{{p0.x, p0.y, p0.z}, {u.x, u.y, u.z}, r}; circles_.push_back(c); return add(RT_HIP_CIRCLE, (uint32_t)circles_.size() - 1, m, col); }
+  int AddTriangle(const Point3D v[3], const Point3D *vn, const Material &m, Colour col)   // Object.h:360-384
+  {
+    rt_hip_triangle t{};
+    for (int i = 0; i < 3; i++) { t.v[i][0] = v[i].x; t.v[i][1] = v[i].y; t.v[i][2] = v[i].z; }
+    if (vn) { for (int i = 0; i < 3; i++) { t.vn[i][0] = vn[i].x; t.vn[i][1] = vn[i].y; t.vn[i][2] = vn[i].z; } t.has_vn = 1; }
+    triangles_.push_back(t);
+    return add(RT_HIP_TRIANGLE, (uint32_t)triangles_.size() - 1, m, col);
+  }
+  // Scene.h:150-166: every face -> CTriangle of its first three tuples, vertex = point*scale + center
+  int ReadObjFile_Triangle(const std::string &filename, Point3D center, double scale, const Material &m, Colour col)
+  {
+    ObjMesh mesh(filename);
+    int added = 0;
+    for (const auto &face : mesh.faces) {
+      if (face.size() < 3) throw std::runtime_error("OBJ face with fewer than 3 vertices");
+      Point3D v[3], vn[3];
+      for (int k = 0; k < 3; k++) {
+        if (face[k].pointIndex < 0 || (size_t)face[k].pointIndex >= mesh.points.size() ||
+            face[k].normIndex < 0 || (size_t)face[k].normIndex >= mesh.normals.size())
+          throw std::runtime_error("OBJ index out of range");
+        v[k] = mesh.points[face[k].pointIndex] * scale + center;
+        vn[k] = mesh.normals[face[k].normIndex];
+      }
+      AddTriangle(v, vn, m, col); added++;
+    }
+    return added;
+  }
+  // ---- lights ----
+  void AddParallelLight(Point3D dir, double lum)                                   // Scene.h:268, Light.h:76-77
+  { Point3D u = dir.Unitize(); rt_hip_light l{RT_HIP_PARALLEL_LIGHT, 0, {u.x, u.y, u.z}, lum, 0}; lights_.push_back(l); dirty_ = true; }
+  void AddPointLight(Point3D pos, double lum)                                      // Scene.h:274
+  { rt_hip_light l{RT_HIP_POINT_LIGHT, 0, {pos.x, pos.y, pos.z}, lum, 0}; lights_.push_back(l); dirty_ = true; }
+  void AddAreaLight(Point3D pos, double lum, double len, int sampleNum)            // Scene.h:280
+  { rt_hip_light l{RT_HIP_AREA_LIGHT, sampleNum, {pos.x, pos.y, pos.z}, lum, len}; lights_.push_back(l); dirty_ = true; }
+
+  // ---- BSP tree: CScene::ConstructBSPTree (Scene.h:286-293) + BSPTree::Subdivide (BSPTree.h:58-109),
+  //      emitted directly as the flattened arrays of rt_hip_scene_desc ----
+  void ConstructBSPTree(int maxObjNum = 100, int maxDepth = 40)
+  {
+    nodes_.clear(); refs_.clear(); root_objects_.clear(); dirty_ = true;
+    compute_boxes();
+    Box big;
+    if (!biggest_aabb(big)) return;                       // no finite object: no tree (Scene.h:289-290)
+    std::vector<uint32_t> all(type_.size());
+    for (uint32_t i = 0; i < all.size(); i++) all[i] = i;
+    max_obj_ = maxObjNum; max_depth_ = maxDepth;
+    subdivide(all, big, 0, 0, true);
+  }
+  bool HasTree() const { return !nodes_.empty(); }
+  size_t NumObjects() const { return type_.size(); }
+  const std::vector<rt_hip_node> &Nodes() const { return nodes_; }
+  const std::vector<uint32_t> &Refs() const { return refs_; }
+  const std::vector<uint32_t> &RootObjects() const { return root_objects_; }
+  const std::vector<rt_hip_triangle> &Triangles() const { return triangles_; }
+
+  // ---- device ----
+  void SetLeafRefine(uint32_t n) { leaf_refine_ = n; dirty_ = true; }
+  rt_hip_scene *Device(Context &ctx)
+  {
+    if (dev_ && !dirty_ && dev_ctx_ == ctx.get()) return dev_;
+    rt_hip_scene_destroy(dev_); dev_ = nullptr;
+    rt_hip_scene_desc d{};
+    d.struct_size = sizeof d;
+    d.n_objects = (uint32_t)type_.size();
+    d.obj_type = type_.data(); d.obj_index = index_.data(); d.obj_material = mat_index_.data(); d.obj_colour = colour_.data();
+    d.n_triangles = (uint32_t)triangles_.size(); d.triangles = triangles_.data();
+    d.n_planes = (uint32_t)planes_.size(); d.planes = planes_.data();
+    d.n_spheres = (uint32_t)spheres_.size(); d.spheres = spheres_.data();
+    d.n_circles = (uint32_t)circles_.size(); d.circles = circles_.data();
+    d.n_materials = (uint32_t)materials_.size(); d.materials = materials_.data();
+    d.n_lights = (uint32_t)lights_.size(); d.lights = lights_.data();
+    d.ambient = ambient_;
+    d.n_nodes = (uint32_t)nodes_.size(); d.nodes = nodes_.data();
+    d.n_refs = (uint32_t)refs_.size(); d.refs = refs_.data();
+    d.n_root_objects = (uint32_t)root_objects_.size(); d.root_objects = root_objects_.data();
+    check(rt_hip_scene_create(ctx.get(), &d, leaf_refine_, &dev_), "rt_hip_scene_create");
+    dev_ctx_ = ctx.get(); dirty_ = false;
+    return dev_;
+  }
+  // CScene::FirstInterPt_BSPTree (Scene.h:85-91) / FirstInterPt (Scene.h:62-83) for a batch of rays
+  void FirstInterPt_BSPTree(Context &ctx, const rt_hip_ray *rays, size_t n, bool record, rt_hip_hit *hits)
+  { check(rt_hip_trace_closest(Device(ctx), rays, n, 1, record ? 1 : 0, hits), "rt_hip_trace_closest"); }
+  void FirstInterPt(Context &ctx, const rt_hip_ray *rays, size_t n, bool record, rt_hip_hit *hits)
+  { check(rt_hip_trace_closest(Device(ctx), rays, n, 0, record ? 1 : 0, hits), "rt_hip_trace_closest"); }
+
+ private:
+  struct Box { double mn[3], mx[3]; };
+  int add(uint8_t type, uint32_t idx, const Material &m, Colour col)
+  {
+    type_.push_back(type); index_.push_back(idx);
+    // materials are de-duplicated by value
+    uint32_t mi = 0;
+    for (; mi < materials_.size(); mi++) if (std::memcmp(&materials_[mi], &m.m, sizeof m.m) == 0) break;
+    if (mi == materials_.size()) materials_.push_back(m.m);
+    mat_index_.push_back(mi);
+    colour_.push_back(col.R); colour_.push_back(col.G); colour_.push_back(col.B);
+    dirty_ = true;
+    return (int)type_.size() - 1;
+  }
+  static bool is_infty_box(const Box &b)
+  { for (int a = 0; a < 3; a++) if (!(std::fabs(b.mn[a] - infty) < eps && std::fabs(b.mx[a] - infty) < eps)) return false; return true; }
+  void compute_boxes()
+  {
+    boxes_.resize(type_.size());
+    for (size_t i = 0; i < type_.size(); i++) {
+      Box b;
+      for (int a = 0; a < 3; a++) { b.mn[a] = infty; b.mx[a] = infty; }                  // Object.h:34
+      if (type_[i] == RT_HIP_TRIANGLE) {                                                  // Object.h:459-468
+        const rt_hip_triangle &t = triangles_[index_[i]];
+        for (int a = 0; a < 3; a++) {
+          b.mn[a] = std::min(std::min(t.v[0][a], t.v[1][a]), t.v[2][a]) - eps;
+          b.mx[a] = std::max(std::max(t.v[0][a], t.v[1][a]), t.v[2][a]) + eps;
+        }
+      } else if (type_[i] == RT_HIP_SPHERE) {                                             // Object.h:234
+        const rt_hip_sphere &s = spheres_[index_[i]];
+        for (int a = 0; a < 3; a++) { b.mn[a] = s.c[a] - s.r; b.mx[a] = s.c[a] + s.r; }
+      }
+      boxes_[i] = b;
+    }
+  }
+  bool biggest_aabb(Box &out) const                                                       // Scene.h:295-317
+  {
+    double mn[3] = {infty, infty, infty}, mx[3] = {-infty, -infty, -infty};
+    for (const Box &b : boxes_) {
+      if (is_infty_box(b)) continue;
+      for (int a = 0; a < 3; a++) { if (b.mn[a] < mn[a]) mn[a] = b.mn[a]; if (b.mx[a] > mx[a]) mx[a] = b.mx[a]; }
+    }
+    auto ne = [](double p, double q) { return !(std::fabs(p - q) < eps); };   // operator!= on doubles is exact in the reference
+    (void)ne;
+    if (mn[0] != infty && mn[1] != infty && mn[2] != infty && mx[0] != -infty && mx[1] != -infty && mx[2] != infty) {
+      for (int a = 0; a < 3; a++) { out.mn[a] = mn[a]; out.mx[a] = mx[a]; }
+      return true;
+    }
+    return false;
+  }
+  bool point_in_box(uint32_t id, const Box &box) const                                     // Object.h:212-222
+  {
+    if (is_infty_box(box)) return true;
+    const Box &b = boxes_[id];
+    for (int a = 0; a < 3; a++) if (b.mn[a] > box.mx[a] + eps || b.mx[a] < box.mn[a] - eps) return false;
+    return true;
+  }
+  // returns the index of the emitted node
+  uint32_t subdivide(std::vector<uint32_t> &objs, const Box &box, int depth, int axis, bool is_root)
+  {
+    const uint32_t me = (uint32_t)nodes_.size();
+    nodes_.emplace_back();
+    {
+      rt_hip_node &n = nodes_[me];
+      for (int a = 0; a < 3; a++) { n.box_min[a] = box.mn[a]; n.box_max[a] = box.mx[a]; }
+      n.split_axis = -1; n.a = 0; n.b = 0; n.reserved = 0;
+    }
+    if ((int)objs.size() < max_obj_ || depth == max_depth_) {                              // BSPTree.h:60
+      nodes_[me].a = (int32_t)refs_.size(); nodes_[me].b = (int32_t)objs.size();
+      refs_.insert(refs_.end(), objs.begin(), objs.end());
+      if (is_root) root_objects_ = objs;                 // an unsplit root keeps every object (BSPTree.h:60-61)
+      return me;
+    }
+    Box L = box, R = box;
+    const double mid = (box.mn[axis] + box.mx[axis]) / 2;                                  // BSPTree.h:71-72 etc.
+    L.mx[axis] = mid; R.mn[axis] = mid;
+    std::vector<uint32_t> lo, ro;
+    for (uint32_t id : objs) {                                                             // BSPTree.h:94-102
+      if (point_in_box(id, L)) lo.push_back(id);
+      if (point_in_box(id, R)) ro.push_back(id);
+      if (is_root && is_infty_box(boxes_[id])) root_objects_.push_back(id);
+    }
+    std::vector<uint32_t>().swap(objs);                                                    // BSPTree.h:103
+    const int next = (axis + 1) % 3;
+    uint32_t l = subdivide(lo, L, depth + 1, next, false);
+    uint32_t r = subdivide(ro, R, depth + 1, next, false);
+    nodes_[me].split_axis = axis; nodes_[me].a = (int32_t)l; nodes_[me].b = (int32_t)r;
+    return me;
+  }
+
+  double ambient_;
+  std::vector<uint8_t> type_; std::vector<uint32_t> index_, mat_index_; std::vector<double> colour_;
+  std::vector<rt_hip_triangle> triangles_; std::vector<rt_hip_plane> planes_; std::vector<rt_hip_sphere> spheres_;
+  std::vector<rt_hip_circle> circles_; std::vector<rt_hip_material> materials_; std::vector<rt_hip_light> lights_;
+  std::vector<Box> boxes_;
+  std::vector<rt_hip_node> nodes_; std::vector<uint32_t> refs_, root_objects_;
+  int max_obj_ = 100, max_depth_ = 40;
+  uint32_t leaf_refine_ = 0;
+  rt_hip_scene *dev_ = nullptr; rt_hip_ctx *dev_ctx_ = nullptr; bool dirty_ = true;
+};
+
+class Camera {                   // CCamera, Camera.h:14-51
+ public:
+  Camera(Point3D viewPt, Point3D eyeDirection, Point3D left, double distOfPlane, double horRange, double verRange,
+         int resolution, int depth)
+  {
+    cam_ = rt_hip_camera{{viewPt.x, viewPt.y, viewPt.z}, {eyeDirection.x, eyeDirection.y, eyeDirection.z}, {left.x, left.y, left.z},
+                         distOfPlane, horRange, verRange, resolution, depth};
+    check(rt_hip_camera_size(&cam_, &w_, &h_), "rt_hip_camera_size");
+  }
+  int width() const { return w_; }
+  int height() const { return h_; }
+  const rt_hip_camera &raw() const { return cam_; }
+  uint64_t seed = 0;
+  // Render_RayTracer, Camera.h:53-75.  rgb(): doubles before the uchar store; image(): the CV_8UC3 picture
+  // (BGR, row-major [v][h][3]) with the reference's double->uchar truncation (Camera.h:69).
+  void Render_RayTracer(Context &ctx, Scene &scene, Colour background = Colour(0, 0, 0))
+  {
+    rt_hip_params p = params(background);
+    rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.assign((size_t)w_ * h_, -1);
+    check(rt_hip_render_whitted(scene.Device(ctx), &cam_, &p, rgb_.data(), prim_.data()), "rt_hip_render_whitted");
+    to_picture();
+  }
+  // Render_Focusing, Camera.h:171-199 (spp = the reference's sampleTimes, default 100)
+  void Render_Focusing(Context &ctx, Scene &scene, double radius, Colour background = Colour(0, 0, 0), uint32_t spp = 100)
+  {
+    rt_hip_params p = params(background);
+    p.spp = spp; p.lens_radius = radius;
+    rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.clear();
+    check(rt_hip_render_focusing(scene.Device(ctx), &cam_, &p, rgb_.data()), "rt_hip_render_focusing");
+    for (double &c : rgb_) c = std::min(255.0, c);        // the running clamp of Colour.h:41-47, applied once
+    to_picture();
+  }
+  const std::vector<double> &rgb() const { return rgb_; }
+  const std::vector<int32_t> &prim_id() const { return prim_; }
+  const std::vector<uint8_t> &image() const { return picture_; }
+  // binary PPM instead of cv::imwrite (Camera.h:73)
+  void WritePPM(const std::string &path) const
+  {
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + path);
+    std::fprintf(f, "P6\n%d %d\n255\n", w_, h_);
+    for (size_t i = 0; i < (size_t)w_ * h_; i++) { uint8_t px[3] = {picture_[3 * i + 2], picture_[3 * i + 1], picture_[3 * i]}; std::fwrite(px, 1, 3, f); }
+    std::fclose(f);
+  }
+ private:
+  rt_hip_params params(Colour bg) const
+  {
+    rt_hip_params p{}; p.struct_size = sizeof p;
+    p.background[0] = bg.R; p.background[1] = bg.G; p.background[2] = bg.B; p.seed = seed;
+    return p;
+  }
+  void to_picture()
+  {
+    picture_.resize((size_t)w_ * h_ * 3);
+    for (size_t i = 0; i < (size_t)w_ * h_; i++) {
+      picture_[3 * i] = (uint8_t)rgb_[3 * i + 2]; picture_[3 * i + 1] = (uint8_t)rgb_[3 * i + 1]; picture_[3 * i + 2] = (uint8_t)rgb_[3 * i];
+    }
+  }
+  rt_hip_camera cam_{}; int w_ = 0, h_ = 0;
+  std::vector<double> rgb_; std::vector<int32_t> prim_; std::vector<uint8_t> picture_;
+};
+
+}}  // namespace rt::host

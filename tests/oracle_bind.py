@@ -1,0 +1,153 @@
+"""ctypes binding of oracle/librt_oracle.so -- the CPU checker (test infrastructure only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_path = os.path.join(ROOT, "oracle", "librt_oracle.so")
+if not os.path.exists(_path):
+    raise ImportError("oracle/librt_oracle.so missing: run `make -C oracle` or `python __graft_entry__.py`")
+L = C.CDLL(_path)
+
+d3 = C.c_double * 3
+d8 = C.c_double * 8
+_vp = C.c_void_p
+
+
+class OrcCamera(C.Structure):
+    _fields_ = [("view_pt", d3), ("eye_dir", d3), ("left_arg", d3), ("dist", C.c_double), ("hor", C.c_double),
+                ("ver", C.c_double), ("res", C.c_int32), ("depth", C.c_int32)]
+
+
+L.orc_scene_new.restype = _vp
+L.orc_scene_new.argtypes = [C.c_double]
+L.orc_scene_free.argtypes = [_vp]
+L.orc_material_preset.argtypes = [C.c_int, d8]
+L.orc_add_sphere.argtypes = [_vp, d3, C.c_double, d8, d3]
+L.orc_add_plane.argtypes = [_vp, d3, d3, d8, d3]
+L.orc_add_circle.argtypes = [_vp, d3, d3, C.c_double, d8, d3]
+L.orc_add_triangle.argtypes = [_vp, _vp, _vp, d8, d3]
+L.orc_read_obj_triangle.argtypes = [_vp, C.c_char_p, d3, C.c_double, d8, d3]
+L.orc_num_objects.argtypes = [_vp]
+L.orc_get_triangle.argtypes = [_vp, C.c_int, _vp, _vp]
+L.orc_add_point_light.argtypes = [_vp, d3, C.c_double]
+L.orc_add_parallel_light.argtypes = [_vp, d3, C.c_double]
+L.orc_add_area_light.argtypes = [_vp, d3, C.c_double, C.c_double, C.c_int]
+L.orc_construct_bsp.argtypes = [_vp, C.c_int, C.c_int]
+L.orc_tree_stats.argtypes = [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+L.orc_rng_u32.restype = C.c_uint32
+L.orc_rng_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+L.orc_trace_closest.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp, _vp, _vp]
+L.orc_camera_size.argtypes = [C.POINTER(OrcCamera), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+L.orc_camera_rays.argtypes = [C.POINTER(OrcCamera), _vp]
+L.orc_render_whitted.argtypes = [_vp, C.POINTER(OrcCamera), d3, C.c_uint64, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]
+L.orc_render_focusing.argtypes = [_vp, C.POINTER(OrcCamera), C.c_double, C.c_int, d3, C.c_uint64, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]
+L.orc_object_first_inter_pt.argtypes = [_vp, C.c_int, _vp, _vp, _vp]
+
+MATERIALS = {"mirror": 200, "glass": 201, "ice": 202, "metal": 203, "porcelain": 204, "rubber": 205, "plastic": 206}
+
+
+def material(name):
+    m = d8()
+    L.orc_material_preset(MATERIALS[name], m)
+    return m
+
+
+def make_camera(view, eye, left, dist, hor, ver, res, depth):
+    return OrcCamera(d3(*view), d3(*eye), d3(*left), dist, hor, ver, res, depth)
+
+
+class OracleScene:
+    def __init__(self, ambient=0.0):
+        self.h = L.orc_scene_new(float(ambient))
+
+    def add_sphere(self, c, r, mat, colour):
+        return L.orc_add_sphere(self.h, d3(*c), r, mat, d3(*colour))
+
+    def add_plane(self, p0, n, mat, colour):
+        return L.orc_add_plane(self.h, d3(*p0), d3(*n), mat, d3(*colour))
+
+    def add_circle(self, p0, n, r, mat, colour):
+        return L.orc_add_circle(self.h, d3(*p0), d3(*n), r, mat, d3(*colour))
+
+    def add_triangle(self, v, vn, mat, colour):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(9)
+        vnp = None
+        if vn is not None:
+            vn = np.ascontiguousarray(vn, dtype=np.float64).reshape(9)
+            vnp = vn.ctypes.data
+        return L.orc_add_triangle(self.h, v.ctypes.data, vnp, mat, d3(*colour))
+
+    def add_triangles(self, v, mat, colour):
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, 9)
+        col = d3(*colour)
+        for k in range(v.shape[0]):
+            L.orc_add_triangle(self.h, v[k].ctypes.data, None, mat, col)
+
+    def read_obj_triangle(self, path, center, scale, mat, colour):
+        n = L.orc_read_obj_triangle(self.h, os.fsencode(path), d3(*center), scale, mat, d3(*colour))
+        if n < 0:
+            raise IOError(path)
+        return n
+
+    def add_point_light(self, p, lum):
+        L.orc_add_point_light(self.h, d3(*p), lum)
+
+    def add_parallel_light(self, d, lum):
+        L.orc_add_parallel_light(self.h, d3(*d), lum)
+
+    def add_area_light(self, p, lum, length, sample_num):
+        L.orc_add_area_light(self.h, d3(*p), lum, length, sample_num)
+
+    def construct_bsp(self, max_obj_num=0, max_depth=0):
+        L.orc_construct_bsp(self.h, max_obj_num, max_depth)
+
+    @property
+    def num_objects(self):
+        return L.orc_num_objects(self.h)
+
+    def tree_stats(self):
+        st = (C.c_int64 * 8)()
+        box = (C.c_double * 6)()
+        L.orc_tree_stats(self.h, st, box)
+        return list(st), list(box)
+
+    def trace_closest(self, rays, use_bsp=True, record=True):
+        r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = r.shape[0]
+        ids = np.zeros(n, np.int32)
+        pts = np.zeros((n, 3))
+        L.orc_trace_closest(self.h, r.ctypes.data, n, int(use_bsp), int(record), ids.ctypes.data, pts.ctypes.data, None)
+        return ids, pts
+
+    def render_whitted(self, cam, background=(0, 0, 0), seed=0, first=0, count=0, threads=0, counters=False):
+        w, h = C.c_int(), C.c_int()
+        L.orc_camera_size(C.byref(cam), C.byref(w), C.byref(h))
+        n = count if count else w.value * h.value
+        rgb = np.zeros((n, 3))
+        ids = np.zeros(n, np.int32)
+        cnt = np.zeros(4, np.int64)
+        L.orc_render_whitted(self.h, C.byref(cam), d3(*background), seed, rgb.ctypes.data, ids.ctypes.data, first, count,
+                             threads, cnt.ctypes.data if counters else None)
+        return (rgb, ids, cnt) if counters else (rgb, ids)
+
+    def render_focusing(self, cam, radius, spp, background=(0, 0, 0), seed=0, first=0, count=0, threads=0):
+        w, h = C.c_int(), C.c_int()
+        L.orc_camera_size(C.byref(cam), C.byref(w), C.byref(h))
+        n = count if count else w.value * h.value
+        rgb = np.zeros((n, 3))
+        L.orc_render_focusing(self.h, C.byref(cam), radius, spp, d3(*background), seed, rgb.ctypes.data, first, count, threads, None)
+        return rgb
+
+    def camera_rays(self, cam):
+        w, h = C.c_int(), C.c_int()
+        L.orc_camera_size(C.byref(cam), C.byref(w), C.byref(h))
+        rays = np.zeros((w.value * h.value, 6))
+        L.orc_camera_rays(C.byref(cam), rays.ctypes.data)
+        return rays, w.value, h.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            L.orc_scene_free(self.h)
+            self.h = None

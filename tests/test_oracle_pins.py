@@ -1,0 +1,28 @@
+"""The oracle against the only outputs of the reference itself that we hold: the figures the surveyor
+recorded in SURVEY.md 8(c) from a probe build of the reference (C1 scene)."""
+import numpy as np
+
+import scenes
+
+
+def test_c1_tree_statistics_match_survey():
+    _, o = scenes.build_icosahedron(gpu=False)
+    st, box = o.tree_stats()
+    # 99 nodes / 50 leaves / 3,565 refs / depth 7 / max leaf 99
+    assert st[0] == 99 and st[1] == 50 and st[3] == 3565 and st[4] == 7 and st[5] == 99
+    assert st[6] == 2          # the two infinite planes stay in root->objects
+    ref = [-0.515054, -1.51519, -1e-8, 0.755054, -0.245084, 1.27011]
+    assert np.allclose(box, ref, rtol=2e-6, atol=1e-12)
+
+
+def test_c1_hit_id_hash_matches_survey():
+    _, o = scenes.build_icosahedron(gpu=False)
+    assert o.num_objects == 1371
+    rays, w, h = o.camera_rays(scenes.oracle_camera(scenes.C1_CAMERA))
+    assert (w, h) == (640, 480)
+    ids, _ = o.trace_closest(rays, use_bsp=True)
+    assert scenes.fnv_hash_ids(ids) == "83db7884e5084a37"
+    assert int((ids >= 2).sum()) == 11914 and int((ids < 0).sum()) == 0
+    # BSP vs brute force: 0 mismatches
+    ids2, _ = o.trace_closest(rays, use_bsp=False)
+    assert (ids == ids2).all()
