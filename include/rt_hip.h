@@ -195,6 +195,21 @@ int rt_hip_render_focusing(rt_hip_scene *scene, const rt_hip_camera *cam, const 
 int rt_hip_render_focusing_dev(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
                                double *d_rgb, void *stream);
 
+/* Per-kernel device time, measured with hipEvents recorded on the caller's stream around every
+ * kernel launch of this scene while profiling is on (rt_hip_set_profiling).  Index = RT_HIP_K_*. */
+#define RT_HIP_K_PRIMARY        0   /* camera/lens ray generation + closest hit (level 0) */
+#define RT_HIP_K_TRACE_NODES    1   /* closest hit of queued secondary rays */
+#define RT_HIP_K_SHADE          2   /* local illumination incl. shadow queries + child ray generation */
+#define RT_HIP_K_COMBINE        3
+#define RT_HIP_K_RESOLVE        4
+#define RT_HIP_K_TRACE_CLOSEST  5   /* rt_hip_trace_closest(_dev) */
+#define RT_HIP_K_TRACE_OCCLUDED 6
+#define RT_HIP_K_COUNT          8
+typedef struct { double ms[RT_HIP_K_COUNT]; uint64_t launches[RT_HIP_K_COUNT]; } rt_hip_profile;
+int rt_hip_set_profiling(rt_hip_scene *scene, int on);
+/* synchronises the device, adds up the recorded events; reset = 1 clears the sums */
+int rt_hip_get_profile(rt_hip_scene *scene, rt_hip_profile *out, int reset);
+
 /* number of rays (closest-hit + occlusion queries) issued by the last render call on this scene */
 int rt_hip_last_ray_count(rt_hip_scene *scene, uint64_t *rays, uint64_t *shadow_rays);
 

@@ -61,6 +61,12 @@ class Stats(C.Structure):
                                           "wave_node_visits", "wave_prim_tests", "reserved")]
 
 
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
+
+
+KERNEL_NAMES = ["k_primary", "k_trace_nodes", "k_shade", "k_combine", "k_resolve", "k_trace_closest", "k_trace_occluded", "-"]
+
 hip.rt_hip_last_error.restype = C.c_char_p
 host.rth_last_error.restype = C.c_char_p
 host.rth_context_raw.restype = C.c_void_p
@@ -119,6 +125,8 @@ hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Pa
 hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_render_focusing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp]
 hip.rt_hip_render_focusing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
+hip.rt_hip_set_profiling.argtypes = [_vp, C.c_int]
+hip.rt_hip_get_profile.argtypes = [_vp, C.POINTER(Profile), C.c_int]
 hip.rt_hip_last_ray_count.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 
 

@@ -75,6 +75,11 @@ struct rt_hip_scene {
   DevBuf counter;                 // queue counter + per-render ray counters
   DevBuf staging;                 // host-pointer entry points
   uint64_t last_rays = 0, last_shadow = 0;
+  // optional per-kernel timing (rt_hip_set_profiling)
+  bool prof_on = false;
+  struct EvPair { hipEvent_t a, b; int k; };
+  std::vector<EvPair> ev_pool; size_t ev_used = 0;
+  rt_hip_profile prof{};
   // tree statistics after refinement (for tests / DESIGN)
   uint32_t n_nodes = 0, n_leaves = 0, n_cull = 0, max_depth = 0;
 };
@@ -586,6 +591,7 @@ extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
   if (!s) return RT_HIP_OK;
   if (s->ctx) (void)hipSetDevice(s->ctx->device);
   for (void *p : s->allocs) (void)hipFree(p);
+  for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &b : s->levels) b.release();
   s->counter.release(); s->staging.release();
   delete s;
@@ -711,6 +717,57 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   return RT_HIP_OK;
 }
 
+// brackets one kernel launch with events when profiling is on
+static int prof_flush(rt_hip_scene *s)
+{
+  if (s->ev_used == 0) return RT_HIP_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  for (size_t i = 0; i < s->ev_used; i++) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[i].a, s->ev_pool[i].b));
+    s->prof.ms[s->ev_pool[i].k] += ms; s->prof.launches[s->ev_pool[i].k]++;
+  }
+  s->ev_used = 0;
+  return RT_HIP_OK;
+}
+struct ProfScope {
+  rt_hip_scene *s; hipStream_t st; rt_hip_scene::EvPair *e = nullptr;
+  ProfScope(rt_hip_scene *s_, int k, hipStream_t st_) : s(s_), st(st_)
+  {
+    if (!s->prof_on) return;
+    if (s->ev_used == s->ev_pool.size()) {
+      if (s->ev_pool.size() >= 8192) { if (prof_flush(s) != RT_HIP_OK) return; }
+      else {
+        rt_hip_scene::EvPair p; p.k = 0;
+        if (hipEventCreate(&p.a) != hipSuccess) return;
+        if (hipEventCreate(&p.b) != hipSuccess) { (void)hipEventDestroy(p.a); return; }
+        s->ev_pool.push_back(p);
+      }
+    }
+    e = &s->ev_pool[s->ev_used++]; e->k = k;
+    (void)hipEventRecord(e->a, st);
+  }
+  ~ProfScope() { if (e) (void)hipEventRecord(e->b, st); }
+};
+
+extern "C" int rt_hip_set_profiling(rt_hip_scene *s, int on)
+{
+  if (!s) return fail(RT_HIP_EINVAL, "NULL argument");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  if (!on) { int rc = prof_flush(s); if (rc) return rc; }
+  s->prof_on = on != 0;
+  return RT_HIP_OK;
+}
+extern "C" int rt_hip_get_profile(rt_hip_scene *s, rt_hip_profile *out, int reset)
+{
+  if (!s || !out) return fail(RT_HIP_EINVAL, "NULL argument");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  int rc = prof_flush(s); if (rc) return rc;
+  *out = s->prof;
+  if (reset) std::memset(&s->prof, 0, sizeof s->prof);
+  return RT_HIP_OK;
+}
+
 static inline unsigned int blocks_for(size_t n) { return (unsigned int)((n + RT_BLOCK - 1) / RT_BLOCK); }
 
 extern "C" int rt_hip_trace_closest_dev(rt_hip_scene *s, const rt_hip_ray *d_rays, size_t n, int use_tree, int record,
@@ -723,6 +780,7 @@ extern "C" int rt_hip_trace_closest_dev(rt_hip_scene *s, const rt_hip_ray *d_ray
   HIP_TRY(hipSetDevice(s->ctx->device));
   DevScene sc = s->dev; if (!use_tree) sc.n_nodes = 0;
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(s, RT_HIP_K_TRACE_CLOSEST, st);
   if (collect_stats) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, sc, d_rays, n, d_hits, s->ctx->d_stats);
   else hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, sc, d_rays, n, d_hits, (Stats *)nullptr);
   HIP_TRY(hipGetLastError());
@@ -754,8 +812,9 @@ extern "C" int rt_hip_trace_occluded(rt_hip_scene *s, const rt_hip_ray *rays, co
   HIP_TRY(hipMemcpy(base, rays, rb, hipMemcpyHostToDevice));
   if (ref_pts) HIP_TRY(hipMemcpy(base + rb, ref_pts, pb, hipMemcpyHostToDevice));
   DevScene sc = s->dev; if (!use_tree) sc.n_nodes = 0;
+  { ProfScope ps(s, RT_HIP_K_TRACE_OCCLUDED, nullptr);
   hipLaunchKernelGGL(k_trace_occluded<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, nullptr, sc, (const rt_hip_ray *)base,
-                     ref_pts ? (const double *)(base + rb) : (const double *)nullptr, n, (uint8_t *)(base + rb + pb), (Stats *)nullptr);
+                     ref_pts ? (const double *)(base + rb) : (const double *)nullptr, n, (uint8_t *)(base + rb + pb), (Stats *)nullptr); }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(occluded, base + rb + pb, n, hipMemcpyDeviceToHost));
   return RT_HIP_OK;
@@ -800,8 +859,11 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   const unsigned int waves = A.tiles_x * A.tiles_y * A.n_samples;
   const unsigned int pblocks = (waves + RT_WAVES - 1) / RT_WAVES;
   PathNode *L0 = (PathNode *)s->levels[0].p;
-  if (stats) hipLaunchKernelGGL(k_primary<true>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, gs);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, gs);
+  {
+    ProfScope ps(s, RT_HIP_K_PRIMARY, st);
+    if (stats) hipLaunchKernelGGL(k_primary<true>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, gs);
+    else hipLaunchKernelGGL(k_primary<false>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, gs);
+  }
   HIP_TRY(hipGetLastError());
   unsigned int n_level[rt_hip_scene::kMaxLevels] = {0};
   n_level[0] = (unsigned int)n0;
@@ -823,11 +885,15 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     HIP_TRY(hipMemsetAsync(&cnt->queue_count, 0, sizeof(unsigned int), st));
     PathNode *cur = (PathNode *)s->levels[lv].p;
     if (lv > 0) {
+      ProfScope ps(s, RT_HIP_K_TRACE_NODES, st);
       if (stats) hipLaunchKernelGGL(k_trace_nodes<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, cur, n, gs);
       else hipLaunchKernelGGL(k_trace_nodes<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, cur, n, gs);
     }
-    if (stats) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, next, next_cap, cnt, gs);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, next, next_cap, cnt, gs);
+    {
+      ProfScope ps(s, RT_HIP_K_SHADE, st);
+      if (stats) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, next, next_cap, cnt, gs);
+      else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, next, next_cap, cnt, gs);
+    }
     HIP_TRY(hipGetLastError());
     if (depth_left > 1) {
       unsigned int qn = 0;
@@ -837,6 +903,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     }
   }
   for (int lv = last - 1; lv >= 0; lv--) {
+    ProfScope ps(s, RT_HIP_K_COMBINE, st);
     hipLaunchKernelGGL(k_combine, dim3(blocks_for(n_level[lv])), dim3(RT_BLOCK), 0, st, (PathNode *)s->levels[lv].p, n_level[lv],
                        (const PathNode *)s->levels[lv + 1].p, A);
     HIP_TRY(hipGetLastError());
@@ -876,7 +943,8 @@ extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *c
   HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
   s->last_rays = 0; s->last_shadow = 0;
   rc = run_levels(s, A, P->collect_stats != 0, st); if (rc) return rc;
-  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, 1.0, 0, d_rgb, d_prim_id);
+  { ProfScope ps(s, RT_HIP_K_RESOLVE, st);
+  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, 1.0, 0, d_rgb, d_prim_id); }
   HIP_TRY(hipGetLastError());
   return RT_HIP_OK;
 }
@@ -900,8 +968,9 @@ extern "C" int rt_hip_render_focusing_dev(rt_hip_scene *s, const rt_hip_camera *
   for (uint32_t done = 0; done < s_count; done += batch) {
     A.sample_first = s_first + done; A.n_samples = std::min(batch, s_count - done);
     rc = run_levels(s, A, P->collect_stats != 0, st); if (rc) return rc;
+    { ProfScope ps(s, RT_HIP_K_RESOLVE, st);
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, (double)spp,
-                       done ? 1 : 0, d_rgb, (int32_t *)nullptr);
+                       done ? 1 : 0, d_rgb, (int32_t *)nullptr); }
     HIP_TRY(hipGetLastError());
   }
   return RT_HIP_OK;
