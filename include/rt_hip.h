@@ -199,11 +199,12 @@ int rt_hip_render_focusing_dev(rt_hip_scene *scene, const rt_hip_camera *cam, co
  * kernel launch of this scene while profiling is on (rt_hip_set_profiling).  Index = RT_HIP_K_*. */
 #define RT_HIP_K_PRIMARY        0   /* camera/lens ray generation + closest hit (level 0) */
 #define RT_HIP_K_TRACE_NODES    1   /* closest hit of queued secondary rays */
-#define RT_HIP_K_SHADE          2   /* local illumination incl. shadow queries + child ray generation */
+#define RT_HIP_K_SHADE          2   /* local illumination + child ray generation */
 #define RT_HIP_K_COMBINE        3
 #define RT_HIP_K_RESOLVE        4
 #define RT_HIP_K_TRACE_CLOSEST  5   /* rt_hip_trace_closest(_dev) */
 #define RT_HIP_K_TRACE_OCCLUDED 6
+#define RT_HIP_K_SHADOW         7   /* luminosity of every light at every hit: occlusion walks */
 #define RT_HIP_K_COUNT          8
 typedef struct { double ms[RT_HIP_K_COUNT]; uint64_t launches[RT_HIP_K_COUNT]; } rt_hip_profile;
 int rt_hip_set_profiling(rt_hip_scene *scene, int on);

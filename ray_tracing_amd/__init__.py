@@ -65,7 +65,7 @@ class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
 
 
-KERNEL_NAMES = ["k_primary", "k_trace_nodes", "k_shade", "k_combine", "k_resolve", "k_trace_closest", "k_trace_occluded", "-"]
+KERNEL_NAMES = ["k_primary", "k_trace_nodes", "k_shade", "k_combine", "k_resolve", "k_trace_closest", "k_trace_occluded", "k_shadow"]
 
 hip.rt_hip_last_error.restype = C.c_char_p
 host.rth_last_error.restype = C.c_char_p

@@ -1,17 +1,17 @@
 // rt_device.hpp -- device-side scene layout, wave-packet BSP traversal and shading for gfx950.
 //
 // Execution model (wave64): one ray per lane, 64 rays per wave walk the tree TOGETHER.  The node
-// stack is wave-uniform (one 32-bit index per entry, kept in LDS), node boxes and the leaf's
-// triangle records are addressed with wave-uniform indices, so the compiler fetches them with
-// scalar loads (s_load_*) and the vector ALU only does per-ray arithmetic.  A lane takes part in a
-// node only if its own ray overlaps the node's box in front of its current best hit; the wave
-// skips a node when no lane wants it (__ballot).  Children are pushed far-first according to the
-// majority ray direction, so the walk is front-to-back for most lanes and every lane prunes with
-// its own best t.
+// stack is wave-uniform (8 bytes per entry, in LDS).  An inner step fetches the boxes of BOTH
+// children with scalar loads (one 128-byte DPair, wave-uniform address) and each lane slab-tests
+// its own ray; a child is pushed only if some lane wants it (__ballot), far child first according
+// to the majority ray direction, so the walk is front-to-back for most lanes and every lane
+// prunes with its own best t.  A leaf is a contiguous stream (header + 192-byte records) that the
+// wave pulls into LDS with direct-to-LDS loads (16 B per lane, all loads of a chunk in flight
+// together) and then reads back as broadcasts.
 //
 // Leaf triangles are tested in two steps:
-//   cull    -- a cheap plane + barycentric test on a precomputed 128-byte record, with margins
-//              that are wide compared with every rounding error involved (see TriCull);
+//   cull    -- a cheap plane + barycentric test on precomputed data, with margins that are wide
+//              compared with every rounding error involved (see LeafRec / leaf_record);
 //   confirm -- the reference's own arithmetic (rt::tri_exact_t, Object.h:416-446) on the raw
 //              vertices, only for lanes that survive the cull.
 // Accepted hits therefore carry exactly the t the reference formula produces.
@@ -21,31 +21,45 @@
 namespace rt {
 
 // ---- device scene ------------------------------------------------------------------------------
-struct alignas(64) DNode {          // 64 B, box inflated by kBoxPad
-  double bmin[3], bmax[3];
-  int32_t axis;                     // >= 0: inner (a = left, b = right); < 0: leaf with (-1-axis) non-triangle refs
-  int32_t a;                        // leaf: first cull record
-  int32_t b;                        // leaf: number of cull records
-  int32_t c;                        // leaf: first entry of leaf_other[]
+// Child descriptor of the flattened tree: i0 >= 0 -> inner node, i0 = index of its DPair;
+// i0 < 0 -> leaf with (-1 - i0) records, i1 = offset of its stream in 64-byte units.
+struct ChildRef { int32_t i0, i1; };
+
+// The two children of one inner node, 128 B = one scalar-cache line pair: both boxes are fetched and
+// tested in ONE step of the walk.  Boxes are tight (cell /\ bounds of the content) and inflated by kBoxPad.
+struct alignas(128) DPair {
+  double lmin[3], lmax[3];
+  double rmin[3], rmax[3];
+  ChildRef l, r;
+  int32_t axis, pad[3];
 };
 
-// Cull record of one triangle reference, 128 B, stored in leaf order (a triangle referenced by k
-// leaves is stored k times so that a leaf is one contiguous stream).
-//   n, dpl    : unit normal m_norm and dpl = dot(v0, n)       -> t' = (dpl - o.n) / (d.n)
-//   B, b0     : beta'  = dot(P', B) + b0                       (dual basis of E1' = v1 - v0)
-//   G, g0     : gamma' = dot(P', G) + g0                       (dual basis of E2' = v2 - v0)
-//   bsum      : |B|_1 + |G|_1 + 1/sin(angle at v0), scales the per-ray margin
-// A record with n = 0 (degenerate or sliver triangle) always goes to the confirm step.
-struct alignas(128) TriCull {
+// Leaf stream: a 64-byte header followed by `count` 192-byte records, contiguous, so that a wave can
+// pull a leaf into LDS with 16-byte-per-lane direct-to-LDS loads (1 KiB per instruction).
+struct alignas(64) LeafHeader { double bmin[3], bmax[3]; int32_t count, pad[3]; };
+
+// One object reference of a leaf (a triangle referenced by k leaves is stored k times).
+//   cull part   : n (= m_norm), dpl = dot(v0,n)  -> t' = (dpl - o.n)/(d.n)
+//                 B,b0 / G,g0 : beta' = dot(P',B)+b0, gamma' = dot(P',G)+g0 (dual basis of v1-v0, v2-v0)
+//                 bsum = |B|_1 + |G|_1 + 1/sin(angle at v0): scales the per-ray barycentric margin
+//   confirm part: v0, v1, v2 for the reference's own arithmetic (Object.h:416-446)
+//   kind        : 0 triangle, 1 triangle that always goes to the confirm step (degenerate / sliver),
+//                 2 any other object type (sphere ...): exact test through object_t()
+struct alignas(64) LeafRec {
   double n[3], dpl;
   double B[3], b0;
   double G[3], g0;
   double bsum;
-  int32_t prim_id, tri_idx;
-  double pad[2];
+  int32_t prim_id, kind;
+  double v0[3], v1[3], v2[3];
+  double pad;
 };
+static_assert(sizeof(DPair) == 128 && sizeof(LeafHeader) == 64 && sizeof(LeafRec) == 192, "layout");
 
-struct alignas(32) TriExact { double v0[3], v1[3], v2[3], nrm[3]; };   // 96 B, by triangle index
+#define RT_CHUNK_RECS 21                 // 64 + 21*192 = 4096 bytes of LDS per wave
+#define RT_CHUNK_BYTES 4096
+
+struct TriExact { double v0[3], v1[3], v2[3], nrm[3]; };               // 96 B, by triangle index (brute force / shading)
 struct TriShade { double vn[3][3]; int32_t has_vn; int32_t pad; };      // vertex normals, by triangle index
 struct DPlane { double p0[3], n[3]; };
 struct DSphere { double c[3], r; };
@@ -54,9 +68,8 @@ struct DMaterial { double reflW, refrW, RI, diff, spec, shiness, emissive, ambie
 struct DLight { int32_t type, sample_num; double p[3], lum, len, lum_per_sample; };
 
 struct DevScene {
-  const DNode *nodes; int32_t n_nodes;          // n_nodes == 0: no tree
-  const TriCull *cull;
-  const int32_t *leaf_other;                    // non-triangle prim ids referenced by leaves
+  const DPair *pairs; const unsigned char *leaf_stream;
+  ChildRef root; int32_t has_tree;              // has_tree == 0: CScene::FirstInterPt over all objects
   const int32_t *root_objs; int32_t n_root_objs;// bspTree.root->objects (infinite objects)
   const TriExact *tri_exact; const TriShade *tri_shade;
   const DPlane *planes; const DSphere *spheres; const DCircle *circles;
@@ -74,6 +87,12 @@ constexpr double kBoxPad = 1e-7;   // spatial inflation of node boxes (covers sl
 constexpr double kGMin = 1e-5;     // |d.n| below this: skip the cull, go to the confirm step
 
 #define RT_STACK_DEPTH 64
+
+// per-wave LDS: the node stack and the staged leaf chunk
+struct WaveLds {
+  alignas(16) unsigned char leaf[RT_CHUNK_BYTES];
+  ChildRef stack[RT_STACK_DEPTH];
+};
 
 // uniform (scalar) copy of a value that is known to be the same in all lanes
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -112,7 +131,7 @@ __device__ __forceinline__ bool occludes(V3 o, V3 d, double t, bool has_ref, V3 
 
 struct RayState {
   V3 o, d;
-  double inv[3];      // 1/d per axis (inf-safe: see slab())
+  V3 inv;             // 1/d per axis, +-1e30 for a (near) zero component so that the slab products stay finite
   double best_t;      // closest accepted t so far (kMiss = none); for ANY mode: upper bound of interest
   int best_id;
   double tmargin;     // per-ray t margin of the cull
@@ -120,10 +139,12 @@ struct RayState {
   double gmin;        // per-ray |d.n| threshold
 };
 
+__device__ __forceinline__ double safe_inv(double x) { return (fabs(x) < 1e-30) ? ((x < 0) ? -1e30 : 1e30) : 1.0 / x; }
+
 __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_scale)
 {
   r.o = o; r.d = d;
-  r.inv[0] = 1.0 / d.x; r.inv[1] = 1.0 / d.y; r.inv[2] = 1.0 / d.z;
+  r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   r.best_t = kMiss; r.best_id = -1;
   double os = dmax(dmax(fabs(o.x), fabs(o.y)), fabs(o.z));
   double s = 1.0 + coord_scale + os;
@@ -132,33 +153,44 @@ __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_
   r.gmin = dmax(kGMin, 1e-7 * s);
 }
 
-// slab test against an (inflated) box; returns false when the ray misses it
-__device__ __forceinline__ bool slab(const RayState &r, const double *bmin, const double *bmax, double &tmin, double &tmax)
+// branch-free slab test against an (inflated) box: does the ray overlap it for some t in (0, best_t]?
+__device__ __forceinline__ bool slab(const RayState &r, const double *bmin, const double *bmax)
 {
-  const double o[3] = {r.o.x, r.o.y, r.o.z};
-  const double d[3] = {r.d.x, r.d.y, r.d.z};
-  tmin = -kMiss; tmax = kMiss;
-  bool ok = true;
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    if (fabs(d[a]) < 1e-30) {           // parallel to the slab: inside or never
-      ok = ok && (o[a] >= bmin[a]) && (o[a] <= bmax[a]);
-    } else {
-      double t1 = (bmin[a] - o[a]) * r.inv[a];
-      double t2 = (bmax[a] - o[a]) * r.inv[a];
-      tmin = fmax(tmin, fmin(t1, t2));
-      tmax = fmin(tmax, fmax(t1, t2));
-    }
-  }
-  return ok && (tmin <= tmax);
+  double t1 = (bmin[0] - r.o.x) * r.inv.x, t2 = (bmax[0] - r.o.x) * r.inv.x;
+  double tmin = fmin(t1, t2), tmax = fmax(t1, t2);
+  t1 = (bmin[1] - r.o.y) * r.inv.y; t2 = (bmax[1] - r.o.y) * r.inv.y;
+  tmin = fmax(tmin, fmin(t1, t2)); tmax = fmin(tmax, fmax(t1, t2));
+  t1 = (bmin[2] - r.o.z) * r.inv.z; t2 = (bmax[2] - r.o.z) * r.inv.z;
+  tmin = fmax(tmin, fmin(t1, t2)); tmax = fmin(tmax, fmax(t1, t2));
+  return (tmin <= tmax) && (tmax > 0.0) && (tmin <= r.best_t);
 }
 
-// One triangle reference for all lanes of the wave.  `want` = lanes for which this leaf matters.
+// direct-to-LDS copy of `bytes` (rounded up to 1 KiB pieces, at most RT_CHUNK_BYTES) from a 16-byte
+// aligned global address; every lane moves 16 bytes per instruction (wave-uniform LDS base + lane*16).
+__device__ __forceinline__ void stage_chunk(const unsigned char *src, unsigned char *lds, int bytes)
+{
+  const int lane = threadIdx.x & 63;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const unsigned char *g = src + lane * 16;
+  __builtin_amdgcn_global_load_lds((glb_void *)g, (lds_void *)lds, 16, 0, 0);
+  if (bytes > 1024) __builtin_amdgcn_global_load_lds((glb_void *)(g + 1024), (lds_void *)(lds + 1024), 16, 0, 0);
+  if (bytes > 2048) __builtin_amdgcn_global_load_lds((glb_void *)(g + 2048), (lds_void *)(lds + 2048), 16, 0, 0);
+  if (bytes > 3072) __builtin_amdgcn_global_load_lds((glb_void *)(g + 3072), (lds_void *)(lds + 3072), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// One staged record for all lanes of the wave; `lane_on` = lanes for which this leaf matters.
 // Returns the confirmed t (kMiss if none) for the calling lane.
 template <bool STATS>
-__device__ __forceinline__ double leaf_triangle(const DevScene &sc, const TriCull &c, const RayState &r, bool want,
-                                                double t_hi, unsigned long long &n_exact)
+__device__ __forceinline__ double leaf_record(const DevScene &sc, const LeafRec &c, const RayState &r, bool lane_on,
+                                              unsigned long long &n_exact)
 {
+  const int kind = uni(c.kind);
+  if (kind == 2) {                                 // sphere etc.: exact test only
+    if (STATS && lane_on) n_exact++;
+    return lane_on ? object_t(sc, uni(c.prim_id), r.o, r.d) : kMiss;
+  }
   // ---- cull (explicit FMAs: this part only has to be conservative) ----
   const double g = fma(r.d.z, c.n[2], fma(r.d.y, c.n[1], r.d.x * c.n[0]));
   const double on = fma(r.o.z, c.n[2], fma(r.o.y, c.n[1], r.o.x * c.n[0]));
@@ -170,16 +202,15 @@ __device__ __forceinline__ double leaf_triangle(const DevScene &sc, const TriCul
   const double be = fma(pz, c.B[2], fma(py, c.B[1], fma(px, c.B[0], c.b0)));
   const double ga = fma(pz, c.G[2], fma(py, c.G[1], fma(px, c.G[0], c.g0)));
   const double m = fma(r.mscale, c.bsum, 1e-6);
-  const bool small_g = !(fabs(g) >= r.gmin);        // also catches n = 0 and NaN
-  const bool inside = (tc > -r.tmargin) && (tc < t_hi + r.tmargin) && (be > -m) && (ga > -m) && (be + ga < 1.0 + m);
-  const bool pass = want && (small_g || inside);
+  const bool small_g = !(fabs(g) >= r.gmin) || (kind == 1);   // also catches NaN
+  const bool inside = (tc > -r.tmargin) && (tc < r.best_t + r.tmargin) && (be > -m) && (ga > -m) && (be + ga < 1.0 + m);
+  const bool pass = lane_on && (small_g || inside);
   double t = kMiss;
   if (pass) {
     // ---- confirm: the reference's arithmetic on the raw vertices ----
     if (STATS) n_exact++;
-    const TriExact &T = sc.tri_exact[c.tri_idx];
-    t = tri_exact_t(mk(T.v0[0], T.v0[1], T.v0[2]), mk(T.v1[0], T.v1[1], T.v1[2]), mk(T.v2[0], T.v2[1], T.v2[2]),
-                    mk(T.nrm[0], T.nrm[1], T.nrm[2]), r.o, r.d);
+    t = tri_exact_t(mk(c.v0[0], c.v0[1], c.v0[2]), mk(c.v1[0], c.v1[1], c.v1[2]), mk(c.v2[0], c.v2[1], c.v2[2]),
+                    mk(c.n[0], c.n[1], c.n[2]), r.o, r.d);
   }
   return t;
 }
@@ -187,11 +218,11 @@ __device__ __forceinline__ double leaf_triangle(const DevScene &sc, const TriCul
 // Packet traversal.  ANY = false: closest hit into r.best_t / r.best_id (Scene.h:85-91 semantics).
 // ANY = true: returns true for a lane as soon as some hit satisfies occludes(); r.best_t must be
 // preset to the largest t of interest (kMiss if unbounded).
-// `stack` points to this wave's RT_STACK_DEPTH ints in LDS.  All lanes of the wave must call this
-// together (inactive rays pass active = false).
+// `lds` is this wave's WaveLds.  All lanes of the wave must call this together (inactive rays pass
+// active = false).
 template <bool ANY, bool STATS>
 __device__ __forceinline__ bool traverse(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref,
-                                         int *stack, Stats &st)
+                                         WaveLds *lds, Stats &st)
 {
   bool found = false;        // ANY mode result
   // update rule shared by every candidate (Scene.h:74-79): first candidate wins ties within eps
@@ -204,49 +235,53 @@ __device__ __forceinline__ bool traverse(const DevScene &sc, RayState &r, bool a
     }
   };
 
-  if (sc.n_nodes > 0) {
+  if (sc.has_tree) {
     int sp = 0;
-    stack[0] = 0; sp = 1;
+    lds->stack[0] = sc.root; sp = 1;
     while (sp > 0) {
-      const int ni = uni(stack[--sp]);
-      const DNode &nd = sc.nodes[ni];
-      double tmin, tmax;
-      bool live = active && !(ANY && found);
-      bool want = live && slab(r, nd.bmin, nd.bmax, tmin, tmax) && (tmax > 0.0) && (tmin <= r.best_t);
-      if (STATS) { if (live) st.node_visits++; if ((threadIdx.x & 63) == 0) st.wave_nodes++; }
-      const unsigned long long wmask = __ballot(want);
-      if (wmask == 0ull) {
-        if (__ballot(live) == 0ull) break;   // every ray of the wave is finished
-        continue;
-      }
-      const int axis = uni(nd.axis);
-      if (axis >= 0) {
-        // inner node: near child first for the majority of the interested lanes
+      --sp;
+      const int i0 = uni(lds->stack[sp].i0), i1 = uni(lds->stack[sp].i1);
+      const bool live = active && !(ANY && found);
+      if (__ballot(live) == 0ull) break;            // every ray of the wave is finished
+      if (i0 >= 0) {
+        // ---- inner node: fetch both child boxes at once, keep the children some lane wants ----
+        const DPair &P = sc.pairs[i0];
+        const bool wl = live && slab(r, P.lmin, P.lmax);
+        const bool wr = live && slab(r, P.rmin, P.rmax);
+        if (STATS) { if (live) st.node_visits += 2; if ((threadIdx.x & 63) == 0) st.wave_nodes += 2; }
+        const unsigned long long ml = __ballot(wl), mr = __ballot(wr);
+        const int axis = uni(P.axis);
         const double da = (axis == 0) ? r.d.x : ((axis == 1) ? r.d.y : r.d.z);
-        const unsigned long long pos = __ballot(want && (da >= 0.0));
-        const bool left_first = (2 * __popcll(pos) >= __popcll(wmask));
-        const int l = uni(nd.a), rr = uni(nd.b);
-        if (sp + 2 <= RT_STACK_DEPTH) {
-          stack[sp++] = left_first ? rr : l;
-          stack[sp++] = left_first ? l : rr;
-        }
+        const unsigned long long pos = __ballot((wl || wr) && (da >= 0.0));
+        const bool left_first = (2 * __popcll(pos) >= __popcll(ml | mr));
+        const ChildRef L = P.l, R = P.r;
+        // push far first so that the near child is popped next
+        if (left_first) { if (mr) lds->stack[sp++] = R; if (ml) lds->stack[sp++] = L; }
+        else            { if (ml) lds->stack[sp++] = L; if (mr) lds->stack[sp++] = R; }
       } else {
-        const int first = uni(nd.a), cnt = uni(nd.b);
-        for (int i = 0; i < cnt; i++) {
-          const TriCull &c = sc.cull[first + i];
-          if (STATS) { if (want) st.prim_tests++; if ((threadIdx.x & 63) == 0) st.wave_prims++; }
-          const bool lane_on = want && !(ANY && found);
-          double t = leaf_triangle<STATS>(sc, c, r, lane_on, r.best_t, st.exact_tests);
-          candidate(t, uni(c.prim_id), lane_on);
-        }
-        const int n_other = -1 - axis;
-        const int ofirst = uni(nd.c);
-        for (int i = 0; i < n_other; i++) {
-          const int id = uni(sc.leaf_other[ofirst + i]);
-          const bool lane_on = want && !(ANY && found);
-          double t = lane_on ? object_t(sc, id, r.o, r.d) : kMiss;
-          if (STATS && lane_on) st.exact_tests++;
-          candidate(t, id, lane_on);
+        // ---- leaf: stage header + records in LDS chunk by chunk ----
+        const int cnt = -1 - i0;
+        const unsigned char *base = sc.leaf_stream + (size_t)(unsigned)i1 * 64;
+        bool want = false;
+        for (int c0 = 0; c0 < cnt; c0 += RT_CHUNK_RECS) {
+          const int nrec = (cnt - c0 < RT_CHUNK_RECS) ? (cnt - c0) : RT_CHUNK_RECS;
+          stage_chunk(base + (size_t)c0 * sizeof(LeafRec), lds->leaf, 64 + nrec * (int)sizeof(LeafRec));
+          if (c0 == 0) {
+            const LeafHeader *H = (const LeafHeader *)lds->leaf;
+            want = live && slab(r, H->bmin, H->bmax);
+            if (STATS) { if (live) st.node_visits++; if ((threadIdx.x & 63) == 0) st.wave_nodes++; }
+            if (__ballot(want) == 0ull) break;
+          }
+          const LeafRec *recs = (const LeafRec *)(lds->leaf + 64);
+          for (int i = 0; i < nrec; i++) {
+            const LeafRec &c = recs[i];
+            const bool lane_on = want && !(ANY && found);
+            if (STATS) { if (lane_on) st.prim_tests++; if ((threadIdx.x & 63) == 0) st.wave_prims++; }
+            double t = leaf_record<STATS>(sc, c, r, lane_on, st.exact_tests);
+            candidate(t, uni(c.prim_id), lane_on);
+          }
+          // the next chunk overwrites the LDS image: all reads above are complete (values consumed)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
       }
     }
@@ -354,7 +389,7 @@ struct RngKey { uint64_t seed; uint32_t pixel, sample, path; };
 // (Scene.h:436-455).  Every shadow query is a wave-packet ANY traversal.
 template <bool STATS>
 __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLight &L, int li, V3 pt, bool active,
-                                                   const RngKey &key, int *stack, Stats &st)
+                                                   const RngKey &key, WaveLds *stack, Stats &st)
 {
   const V3 lp = mk(L.p[0], L.p[1], L.p[2]);
   const int type = uni(L.type);
@@ -389,29 +424,26 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
   return lum;
 }
 
-// CScene::LocalIllumination, Scene.h:93-122 (untextured: objColour = m_colour)
-template <bool STATS>
-__device__ __forceinline__ Col local_illumination(const DevScene &sc, V3 o, V3 d, int id, V3 pt, bool active,
-                                                  const RngKey &key, int *stack, Stats &st, V3 &N_out)
+// CScene::LocalIllumination, Scene.h:93-122 (untextured: objColour = m_colour).  lum[li] = luminosity of
+// light li at pt, computed beforehand by the shadow pass (light_luminosity).
+__device__ __forceinline__ Col local_illumination(const DevScene &sc, V3 d, int id, V3 pt, const double *lum, V3 &N_out)
 {
   Col colour = mkc(0, 0, 0);
-  const int sid = active ? id : 0;
-  V3 N = object_norm(sc, sid, pt);
+  V3 N = object_norm(sc, id, pt);
   N_out = N;
   V3 norm = N;
   if (dot(d, norm) > kEps) norm = neg(norm);
-  const DMaterial M = sc.materials[sc.obj_mat[sid]];
-  const Col oc = mkc(sc.obj_colour[3 * sid], sc.obj_colour[3 * sid + 1], sc.obj_colour[3 * sid + 2]);
+  const DMaterial M = sc.materials[sc.obj_mat[id]];
+  const Col oc = mkc(sc.obj_colour[3 * id], sc.obj_colour[3 * id + 1], sc.obj_colour[3 * id + 2]);
   const V3 refl = reflect_dir(N, d);
   for (int li = 0; li < sc.n_lights; li++) {
     const DLight &L = sc.lights[li];
-    double lum = light_luminosity<STATS>(sc, L, li, pt, active, key, stack, st);
+    const double l = lum[li];
     V3 ldir = (L.type == 101) ? mk(L.p[0], L.p[1], L.p[2]) : unitize(pt - mk(L.p[0], L.p[1], L.p[2]));
-    double diffuse = M.diff * dmax(0.0, -dot(norm, ldir) * lum);
-    double specular = M.spec * lum * pow(dmax(0.0, -dot(ldir, refl)), M.shiness);
+    double diffuse = M.diff * dmax(0.0, -dot(norm, ldir) * l);
+    double specular = M.spec * l * pow(dmax(0.0, -dot(ldir, refl)), M.shiness);
     colour = cadd(colour, cmul(oc, M.emissive + sc.ambient * M.ambient + diffuse + specular));
   }
-  (void)o;
   return colour;
 }
 

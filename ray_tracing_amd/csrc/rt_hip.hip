@@ -72,6 +72,7 @@ struct rt_hip_scene {
   // render workspace (grow-only, reused between calls)
   static constexpr int kMaxLevels = 16;
   DevBuf levels[kMaxLevels];
+  DevBuf lum;                     // per node, per light luminosity (shadow pass -> shade pass)
   DevBuf counter;                 // queue counter + per-render ray counters
   DevBuf staging;                 // host-pointer entry points
   uint64_t last_rays = 0, last_shadow = 0;
@@ -98,12 +99,12 @@ struct Builder {
   uint32_t leaf_refine;
   std::vector<Box> aabb;            // per object (finite ones)
   std::vector<uint8_t> finite;
-  std::vector<DNode> nodes;
-  std::vector<TriCull> cull;
-  std::vector<int32_t> leaf_other;
+  std::vector<DPair> pairs;
+  std::vector<unsigned char> stream;   // leaf headers + records
   std::vector<TriExact> tri_exact;
-  uint32_t n_leaves = 0, max_depth = 0;
+  uint32_t n_leaves = 0, max_depth = 0, n_recs = 0;
   std::string err;
+  struct Sub { ChildRef ref; Box box; bool empty; };
 
   // object AABBs as the reference builds them: CTriangle::InitializeAABB (Object.h:459-468),
   // CSphere ctor (Object.h:234); planes and circles keep the infinite default (Object.h:34)
@@ -139,11 +140,15 @@ struct Builder {
     return true;
   }
 
-  TriCull make_cull(uint32_t prim, uint32_t tri) const
+  LeafRec make_rec(uint32_t prim) const
   {
-    TriCull c; std::memset(&c, 0, sizeof c);
-    c.prim_id = (int32_t)prim; c.tri_idx = (int32_t)tri;
-    const TriExact &T = tri_exact[tri];
+    LeafRec c; std::memset(&c, 0, sizeof c);
+    c.prim_id = (int32_t)prim;
+    if (d->obj_type[prim] != RT_HIP_TRIANGLE) { c.kind = 2; return c; }
+    const TriExact &T = tri_exact[d->obj_index[prim]];
+    std::memcpy(c.v0, T.v0, 24); std::memcpy(c.v1, T.v1, 24); std::memcpy(c.v2, T.v2, 24);
+    std::memcpy(c.n, T.nrm, 24);     // m_norm, needed by the confirm step in every case
+    c.kind = 1;                      // until the cull data prove usable
     V3 v0 = mk(T.v0[0], T.v0[1], T.v0[2]), v1 = mk(T.v1[0], T.v1[1], T.v1[2]), v2 = mk(T.v2[0], T.v2[1], T.v2[2]);
     V3 n = mk(T.nrm[0], T.nrm[1], T.nrm[2]);
     V3 e1 = v1 - v0, e2 = v2 - v0;
@@ -152,55 +157,65 @@ struct Builder {
     double l1 = len(e1), l2 = len(e2);
     bool ok = std::isfinite(nn) && nn > 0 && !is_infty_pt(n) && std::isfinite(n.x) && l1 > 0 && l2 > 0;
     double sinv = ok ? (l1 * l2) / std::sqrt(nn) : 1e30;   // 1/sin(angle at v0)
-    if (!ok || sinv > 1e3) return c;                       // n = 0: always confirm
+    if (!ok || sinv > 1e3) return c;
     // dual basis: beta = dot(P - v0, B), gamma = dot(P - v0, G) with B = (e2 x N)/|N|^2, G = (N x e1)/|N|^2
     V3 B = cross(e2, N) / nn, G = cross(N, e1) / nn;
-    c.n[0] = n.x; c.n[1] = n.y; c.n[2] = n.z; c.dpl = dot(v0, n);
-    c.B[0] = B.x; c.B[1] = B.y; c.B[2] = B.z; c.b0 = -dot(v0, B);
-    c.G[0] = G.x; c.G[1] = G.y; c.G[2] = G.z; c.g0 = -dot(v0, G);
-    c.bsum = std::fabs(B.x) + std::fabs(B.y) + std::fabs(B.z) + std::fabs(G.x) + std::fabs(G.y) + std::fabs(G.z) + sinv;
-    if (!std::isfinite(c.bsum) || !std::isfinite(c.b0) || !std::isfinite(c.g0)) { TriCull z; std::memset(&z, 0, sizeof z); z.prim_id = c.prim_id; z.tri_idx = c.tri_idx; return z; }
+    double bsum = std::fabs(B.x) + std::fabs(B.y) + std::fabs(B.z) + std::fabs(G.x) + std::fabs(G.y) + std::fabs(G.z) + sinv;
+    double b0 = -dot(v0, B), g0 = -dot(v0, G), dpl = dot(v0, n);
+    if (!std::isfinite(bsum) || !std::isfinite(b0) || !std::isfinite(g0) || !std::isfinite(dpl)) return c;
+    c.dpl = dpl;
+    c.B[0] = B.x; c.B[1] = B.y; c.B[2] = B.z; c.b0 = b0;
+    c.G[0] = G.x; c.G[1] = G.y; c.G[2] = G.z; c.g0 = g0;
+    c.bsum = bsum; c.kind = 0;
     return c;
   }
 
-  // emits a leaf for the object list `objs` in kd cell `cell`; returns node index or -1 if empty
-  int emit_leaf(const std::vector<uint32_t> &objs, const Box &cell, uint32_t depth)
+  // emits a leaf for the object list `objs` in kd cell `cell`
+  Sub emit_leaf(const std::vector<uint32_t> &objs, const Box &cell, uint32_t depth)
   {
-    if (objs.empty()) return -1;
-    DNode nd; std::memset(&nd, 0, sizeof nd);
+    Sub out; out.empty = objs.empty(); out.ref = ChildRef{0, 0}; out.box = cell;
+    if (out.empty) return out;
+    if (objs.size() > 0x7FFFFFF0u) { err = "leaf too large"; out.empty = true; return out; }
     Box u; for (int a = 0; a < 3; a++) { u.mn[a] = 1e300; u.mx[a] = -1e300; }
-    int first_c = (int)cull.size(), first_o = (int)leaf_other.size(), n_other = 0;
-    for (uint32_t id : objs) {
+    for (uint32_t id : objs)
       for (int a = 0; a < 3; a++) { u.mn[a] = std::min(u.mn[a], aabb[id].mn[a]); u.mx[a] = std::max(u.mx[a], aabb[id].mx[a]); }
-      if (d->obj_type[id] == RT_HIP_TRIANGLE) cull.push_back(make_cull(id, d->obj_index[id]));
-      else { leaf_other.push_back((int32_t)id); n_other++; }
-    }
+    LeafHeader H; std::memset(&H, 0, sizeof H);
     for (int a = 0; a < 3; a++) {
       // every hit point of a referenced object inside this cell lies in cell /\ union(AABB)
-      nd.bmin[a] = std::max(cell.mn[a], u.mn[a]) - kBoxPad;
-      nd.bmax[a] = std::min(cell.mx[a], u.mx[a]) + kBoxPad;
+      H.bmin[a] = std::max(cell.mn[a], u.mn[a]) - kBoxPad;
+      H.bmax[a] = std::min(cell.mx[a], u.mx[a]) + kBoxPad;
+      out.box.mn[a] = H.bmin[a]; out.box.mx[a] = H.bmax[a];
     }
-    nd.axis = -1 - n_other; nd.a = first_c; nd.b = (int)cull.size() - first_c; nd.c = first_o;
-    nodes.push_back(nd);
-    n_leaves++; max_depth = std::max(max_depth, depth);
-    return (int)nodes.size() - 1;
+    H.count = (int32_t)objs.size();
+    size_t off = stream.size();
+    if (off / 64 > 0x7FFFFFFFu) { err = "leaf stream too large"; out.empty = true; return out; }
+    stream.resize(off + 64 + objs.size() * sizeof(LeafRec));
+    std::memcpy(&stream[off], &H, 64);
+    LeafRec *recs = (LeafRec *)&stream[off + 64];
+    for (size_t i = 0; i < objs.size(); i++) recs[i] = make_rec(objs[i]);
+    out.ref.i0 = -1 - (int32_t)objs.size(); out.ref.i1 = (int32_t)(off / 64);
+    n_leaves++; n_recs += (uint32_t)objs.size(); max_depth = std::max(max_depth, depth);
+    return out;
   }
-  int emit_inner(int axis, int l, int r, uint32_t depth)
+  Sub emit_inner(int axis, int slot, const Sub &l, const Sub &r, uint32_t depth)
   {
-    if (l < 0) return r;
-    if (r < 0) return l;
-    DNode nd; std::memset(&nd, 0, sizeof nd);
-    for (int a = 0; a < 3; a++) {
-      nd.bmin[a] = std::min(nodes[l].bmin[a], nodes[r].bmin[a]);
-      nd.bmax[a] = std::max(nodes[l].bmax[a], nodes[r].bmax[a]);
+    // `slot` was reserved before the children were built (parents precede children in memory)
+    if (l.empty || r.empty) {
+      // the reserved slot stays unused when a side is empty: mark it harmless
+      std::memset(&pairs[slot], 0, sizeof(DPair));
+      return l.empty ? r : l;
     }
-    nd.axis = axis; nd.a = l; nd.b = r;
-    nodes.push_back(nd);
+    DPair P; std::memset(&P, 0, sizeof P);
+    for (int a = 0; a < 3; a++) { P.lmin[a] = l.box.mn[a]; P.lmax[a] = l.box.mx[a]; P.rmin[a] = r.box.mn[a]; P.rmax[a] = r.box.mx[a]; }
+    P.l = l.ref; P.r = r.ref; P.axis = axis;
+    pairs[slot] = P;
+    Sub out; out.empty = false; out.ref = ChildRef{slot, 0};
+    for (int a = 0; a < 3; a++) { out.box.mn[a] = std::min(l.box.mn[a], r.box.mn[a]); out.box.mx[a] = std::max(l.box.mx[a], r.box.mx[a]); }
     max_depth = std::max(max_depth, depth);
-    return (int)nodes.size() - 1;
+    return out;
   }
   // continues BSPTree::Subdivide (BSPTree.h:58-109) below a reference leaf, down to leaf_refine objects
-  int refine(std::vector<uint32_t> &objs, const Box &cell, uint32_t depth)
+  Sub refine(std::vector<uint32_t> &objs, const Box &cell, uint32_t depth)
   {
     if (leaf_refine == 0 || objs.size() < leaf_refine || depth >= 56) return emit_leaf(objs, cell, depth);
     int axis = (int)(depth % 3);
@@ -212,33 +227,37 @@ struct Builder {
     // stop when the split no longer separates anything (all objects straddle the plane)
     if (lo.size() == objs.size() && ro.size() == objs.size()) return emit_leaf(objs, cell, depth);
     std::vector<uint32_t>().swap(objs);
-    int l = refine(lo, L, depth + 1);
-    int r = refine(ro, R, depth + 1);
-    return emit_inner(axis, l, r, depth);
+    int slot = (int)pairs.size(); pairs.emplace_back();
+    Sub l = refine(lo, L, depth + 1);
+    Sub r = refine(ro, R, depth + 1);
+    return emit_inner(axis, slot, l, r, depth);
   }
   // walks the reference tree of the description
-  int walk(uint32_t ni, uint32_t depth)
+  Sub walk(uint32_t ni, uint32_t depth)
   {
-    if (ni >= d->n_nodes) { err = "node index out of range"; return -1; }
+    Sub bad; bad.empty = true; bad.ref = ChildRef{0, 0};
+    if (ni >= d->n_nodes) { err = "node index out of range"; return bad; }
     const rt_hip_node &n = d->nodes[ni];
     Box cell; for (int a = 0; a < 3; a++) { cell.mn[a] = n.box_min[a]; cell.mx[a] = n.box_max[a]; }
-    if (depth > 56) { err = "tree deeper than 56 levels"; return -1; }
+    bad.box = cell;
+    if (depth > 56) { err = "tree deeper than 56 levels"; return bad; }
     if (n.split_axis < 0) {
-      if (n.a < 0 || n.b < 0 || (uint64_t)n.a + (uint64_t)n.b > d->n_refs) { err = "leaf ref range out of bounds"; return -1; }
+      if (n.a < 0 || n.b < 0 || (uint64_t)n.a + (uint64_t)n.b > d->n_refs) { err = "leaf ref range out of bounds"; return bad; }
       std::vector<uint32_t> objs;
       for (int i = 0; i < n.b; i++) {
         uint32_t id = d->refs[n.a + i];
-        if (id >= d->n_objects) { err = "leaf ref out of range"; return -1; }
+        if (id >= d->n_objects) { err = "leaf ref out of range"; return bad; }
         if (finite[id]) objs.push_back(id);   // infinite objects only reach the device through root_objects
       }
       return refine(objs, cell, depth);
     }
-    if (n.split_axis > 2 || n.a <= (int)ni || n.b <= (int)ni) { err = "bad inner node"; return -1; }
-    int l = walk((uint32_t)n.a, depth + 1);
-    if (!err.empty()) return -1;
-    int r = walk((uint32_t)n.b, depth + 1);
-    if (!err.empty()) return -1;
-    return emit_inner(n.split_axis, l, r, depth);
+    if (n.split_axis > 2 || n.a <= (int)ni || n.b <= (int)ni) { err = "bad inner node"; return bad; }
+    int slot = (int)pairs.size(); pairs.emplace_back();
+    Sub l = walk((uint32_t)n.a, depth + 1);
+    if (!err.empty()) return bad;
+    Sub r = walk((uint32_t)n.b, depth + 1);
+    if (!err.empty()) return bad;
+    return emit_inner(n.split_axis, slot, l, r, depth);
   }
 };
 
@@ -294,8 +313,8 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(DevScene sc, const rt_hip_ray *rays, size_t n, rt_hip_hit *hits, Stats *gstats)
 {
-  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
-  int *stack = s_stack[threadIdx.x >> 6];
+  __shared__ WaveLds s_lds[RT_WAVES];
+  WaveLds *stack = &s_lds[threadIdx.x >> 6];
   const size_t i = (size_t)xcd_remap(blockIdx.x, gridDim.x) * RT_BLOCK + threadIdx.x;
   const bool active = i < n;
   Stats st{};
@@ -316,8 +335,8 @@ template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_trace_occluded(DevScene sc, const rt_hip_ray *rays, const double *ref_pts, size_t n,
                                                               uint8_t *occluded, Stats *gstats)
 {
-  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
-  int *stack = s_stack[threadIdx.x >> 6];
+  __shared__ WaveLds s_lds[RT_WAVES];
+  WaveLds *stack = &s_lds[threadIdx.x >> 6];
   const size_t i = (size_t)xcd_remap(blockIdx.x, gridDim.x) * RT_BLOCK + threadIdx.x;
   const bool active = i < n;
   Stats st{};
@@ -349,8 +368,8 @@ struct RenderArgs {
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, RenderArgs A, PathNode *nodes, Stats *gstats)
 {
-  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
-  int *stack = s_stack[threadIdx.x >> 6];
+  __shared__ WaveLds s_lds[RT_WAVES];
+  WaveLds *stack = &s_lds[threadIdx.x >> 6];
   const unsigned int wave = xcd_remap(blockIdx.x, gridDim.x) * RT_WAVES + (threadIdx.x >> 6);
   const unsigned int lane = threadIdx.x & 63;
   const unsigned int tiles = A.tiles_x * A.tiles_y;
@@ -389,8 +408,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, RenderArgs A,
 template <bool STATS>
 __global__ void __launch_bounds__(RT_BLOCK) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n, Stats *gstats)
 {
-  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
-  int *stack = s_stack[threadIdx.x >> 6];
+  __shared__ WaveLds s_lds[RT_WAVES];
+  WaveLds *stack = &s_lds[threadIdx.x >> 6];
   const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
   const bool active = i < n;
   Stats st{};
@@ -403,53 +422,75 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_nodes(DevScene sc, PathNode 
   if (STATS) stats_flush(gstats, st);
 }
 
-// RayTracer (RayTracer.h:8-55) for one level of the ray tree: local illumination (with its shadow
-// queries) and generation of the refracted / reflected child rays into the next level's queue.
+// Shadow pass: luminosity of every light at every hit node (Scene.h:104-109), one wave-packet
+// occlusion walk per light sample.  Kept apart from k_shade so that the walk runs at full occupancy.
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, PathNode *nodes, unsigned int n, int depth_left,
-                                                     PathNode *next, unsigned int next_cap, RenderCounters *cnt, Stats *gstats)
+__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n, double *lum,
+                                                      RenderCounters *cnt, Stats *gstats)
 {
-  __shared__ int s_stack[RT_WAVES][RT_STACK_DEPTH];
-  int *stack = s_stack[threadIdx.x >> 6];
+  __shared__ WaveLds s_lds[RT_WAVES];
+  WaveLds *stack = &s_lds[threadIdx.x >> 6];
   const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
   const bool in_range = i < n;
   Stats st{};
+  int id = -1; double t = kMiss; V3 o = mk(0, 0, 0), d = mk(1, 0, 0);
+  RngKey key; key.seed = A.seed; key.pixel = 0; key.sample = 0; key.path = 1;
+  if (in_range) {
+    const PathNode &nd = nodes[i];
+    id = nd.id; t = nd.t; o = mk(nd.o[0], nd.o[1], nd.o[2]); d = mk(nd.d[0], nd.d[1], nd.d[2]);
+    key.pixel = nd.pixel; key.sample = nd.sample; key.path = nd.path;
+  }
+  const bool hit = in_range && id >= 0;
+  const V3 pt = hit ? (o + d * t) : mk(0, 0, 0);     // ray.beginPt() + ray.direction() * t
+  unsigned long long my_shadow = 0;
+  for (int li = 0; li < sc.n_lights; li++) {
+    const DLight &L = sc.lights[li];
+    double l = light_luminosity<STATS>(sc, L, li, pt, hit, key, stack, st);
+    if (hit) { lum[(size_t)i * sc.n_lights + li] = l; my_shadow += (L.type == 102) ? (unsigned long long)L.sample_num * L.sample_num : 1ull; }
+  }
+  // ray census (always on: it is what rt_hip_last_ray_count reports)
+  for (int off = 32; off > 0; off >>= 1) my_shadow += __shfl_down(my_shadow, off, 64);
+  if ((threadIdx.x & 63) == 0 && my_shadow) atomicAdd(&cnt->shadow_rays, my_shadow);
+  if (STATS) stats_flush(gstats, st);
+}
+
+// RayTracer (RayTracer.h:8-55) for one level of the ray tree: local illumination from the luminosities of
+// the shadow pass and generation of the refracted / reflected child rays into the next level's queue.
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, PathNode *nodes, unsigned int n, int depth_left,
+                                                     const double *lum, PathNode *next, unsigned int next_cap, RenderCounters *cnt)
+{
+  const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+  const bool in_range = i < n;
   PathNode nd;
   if (in_range) nd = nodes[i];
   else { nd.id = -1; nd.t = kMiss; nd.weight = 0; nd.pixel = 0; nd.sample = 0; nd.path = 1; for (int k = 0; k < 3; k++) { nd.o[k] = 0; nd.d[k] = (k == 0); } }
   const bool hit = in_range && nd.id >= 0;
   const V3 o = mk(nd.o[0], nd.o[1], nd.o[2]), d = mk(nd.d[0], nd.d[1], nd.d[2]);
   const V3 pt = hit ? (o + d * nd.t) : mk(0, 0, 0);     // ray.beginPt() + ray.direction() * t
-  RngKey key; key.seed = A.seed; key.pixel = nd.pixel; key.sample = nd.sample; key.path = nd.path;
-  V3 N;
-  Stats st0 = st;
-  Col c = local_illumination<STATS>(sc, o, d, nd.id, pt, hit, key, stack, st, N);
-  unsigned long long my_shadow = 0;
-  {
-    // shadow-ray census for rt_hip_last_ray_count: one query per light sample per hit node
-    if (hit) for (int li = 0; li < sc.n_lights; li++) { const DLight &L = sc.lights[li]; my_shadow += (L.type == 102) ? (unsigned long long)L.sample_num * L.sample_num : 1ull; }
-  }
-  (void)st0;
+  V3 N = mk(0, 0, 1);
+  Col c = mkc(A.bg[0], A.bg[1], A.bg[2]);
   int child_refr = -1, child_refl = -1; double w_refr = 0, w_refl = 0;
   bool want_refr = false, want_refl = false; V3 dir_refr = mk(0, 0, 0), dir_refl = mk(0, 0, 0);
-  if (!hit) { c = mkc(A.bg[0], A.bg[1], A.bg[2]); }
-  else if (depth_left > 1) {
-    const DMaterial M = sc.materials[sc.obj_mat[nd.id]];
-    double refrW = M.refrW, reflW = M.reflW;
-    if (!(M.reflW == 0 || M.refrW == 0)) {             // Fresnel, Object.h:130-131, 159-160
-      double R = fresnel_R(N, d, M.RI);
-      reflW = R; refrW = 1 - R;
-    }
-    bool total_reflect = false;
-    if (refrW != 0) {
-      V3 t = refract_dir(N, d, M.RI);
-      if (!is_infty_pt(t)) { w_refr = refrW; dir_refr = t; if (nd.weight * refrW < A.weight_threshold) child_refr = -2; else want_refr = true; }
-      else total_reflect = true;
-    }
-    if (reflW != 0) {
-      dir_refl = reflect_dir(N, d);
-      w_refl = total_reflect ? (reflW + refrW) : reflW;
-      if (nd.weight * w_refl < A.weight_threshold) child_refl = -2; else want_refl = true;
+  if (hit) {
+    c = local_illumination(sc, d, nd.id, pt, lum + (size_t)i * sc.n_lights, N);
+    if (depth_left > 1) {
+      const DMaterial M = sc.materials[sc.obj_mat[nd.id]];
+      double refrW = M.refrW, reflW = M.reflW;
+      if (!(M.reflW == 0 || M.refrW == 0)) {             // Fresnel, Object.h:130-131, 159-160
+        double R = fresnel_R(N, d, M.RI);
+        reflW = R; refrW = 1 - R;
+      }
+      bool total_reflect = false;
+      if (refrW != 0) {
+        V3 t = refract_dir(N, d, M.RI);
+        if (!is_infty_pt(t)) { w_refr = refrW; dir_refr = t; if (nd.weight * refrW < A.weight_threshold) child_refr = -2; else want_refr = true; }
+        else total_reflect = true;
+      }
+      if (reflW != 0) {
+        dir_refl = reflect_dir(N, d);
+        w_refl = total_reflect ? (reflW + refrW) : reflW;
+        if (nd.weight * w_refl < A.weight_threshold) child_refl = -2; else want_refl = true;
+      }
     }
   }
   // wave-aggregated append of the child rays to the next level
@@ -487,13 +528,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, P
     w.col[0] = c.r; w.col[1] = c.g; w.col[2] = c.b;
     w.w_refr = w_refr; w.w_refl = w_refl; w.child_refr = child_refr; w.child_refl = child_refl;
   }
-  // ray census (always on: it is what rt_hip_last_ray_count reports)
-  {
-    unsigned long long x = my_shadow;
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    if (lane == 0 && x) atomicAdd(&cnt->shadow_rays, x);
-  }
-  if (STATS) stats_flush(gstats, st);
 }
 
 // bottom-up composition with the reference's clamped colour arithmetic (RayTracer.h:33, 45, 50)
@@ -593,7 +627,7 @@ extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
   for (void *p : s->allocs) (void)hipFree(p);
   for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &b : s->levels) b.release();
-  s->counter.release(); s->staging.release();
+  s->counter.release(); s->staging.release(); s->lum.release();
   delete s;
   return RT_HIP_OK;
 }
@@ -652,31 +686,24 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   B.object_boxes();
   double cs = 0;
   std::vector<int32_t> root_objs;
-  if (d->n_nodes) {
-    int root = B.walk(0, 0);
+  ChildRef root_ref{0, 0};
+  bool has_tree = d->n_nodes != 0;
+  if (has_tree) {
+    Builder::Sub root = B.walk(0, 0);
     if (!B.err.empty()) { rt_hip_scene_destroy(s); return fail(RT_HIP_EINVAL, "tree: " + B.err); }
-    // the device walk starts at node 0: move the root there
-    if (root >= 0) {
-      std::vector<DNode> re; re.reserve(B.nodes.size());
-      // reverse order puts the root first; children indices are remapped accordingly
-      const int N = (int)B.nodes.size();
-      // root is the last node emitted unless pruning returned a child; make a generic remap via BFS
-      std::vector<int> order, map(N, -1);
-      order.push_back(root); map[root] = 0;
-      for (size_t q = 0; q < order.size(); q++) {
-        const DNode &nd = B.nodes[order[q]];
-        if (nd.axis >= 0) { map[nd.a] = (int)order.size(); order.push_back(nd.a); map[nd.b] = (int)order.size(); order.push_back(nd.b); }
-      }
-      for (int oi : order) { DNode nd = B.nodes[oi]; if (nd.axis >= 0) { nd.a = map[nd.a]; nd.b = map[nd.b]; } re.push_back(nd); }
-      B.nodes.swap(re);
-      for (int a = 0; a < 3; a++) cs = std::max(cs, std::max(std::fabs(B.nodes[0].bmin[a]), std::fabs(B.nodes[0].bmax[a])));
-    } else B.nodes.clear();
-    if (B.nodes.empty()) {
-      // a tree without finite content: keep one empty leaf so that "has tree" semantics (Scene.h:87) hold
-      DNode nd; std::memset(&nd, 0, sizeof nd); nd.axis = -1;
-      for (int a = 0; a < 3; a++) { nd.bmin[a] = 1e300; nd.bmax[a] = -1e300; }
-      B.nodes.push_back(nd);
+    if (root.empty) {
+      // a tree without finite content: one empty leaf keeps the "has tree" semantics (Scene.h:87)
+      LeafHeader H; std::memset(&H, 0, sizeof H);
+      for (int a = 0; a < 3; a++) { H.bmin[a] = 1e300; H.bmax[a] = -1e300; }
+      size_t off = B.stream.size(); B.stream.resize(off + 64); std::memcpy(&B.stream[off], &H, 64);
+      root_ref = ChildRef{-1, (int32_t)(off / 64)};
+    } else {
+      root_ref = root.ref;
+      for (int a = 0; a < 3; a++) cs = std::max(cs, std::max(std::fabs(root.box.mn[a]), std::fabs(root.box.mx[a])));
     }
+    if (B.pairs.empty()) B.pairs.emplace_back();
+    // slack so that the fixed-size direct-to-LDS chunk loads never read past the allocation
+    B.stream.resize(B.stream.size() + 2 * RT_CHUNK_BYTES, 0);
     // root->objects: when the reference root was never split it holds ALL objects (BSPTree.h:60); finite
     // ones are already in the root leaf, so only the infinite ones are kept for the per-ray list
     for (uint32_t i = 0; i < d->n_root_objects; i++) if (!B.finite[d->root_objects[i]]) root_objs.push_back((int32_t)d->root_objects[i]);
@@ -703,16 +730,16 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   DevScene &D = s->dev;
   int rc = RT_HIP_OK;
   auto up = [&](int r) { if (rc == RT_HIP_OK) rc = r; };
-  up(upload(s, B.nodes, &D.nodes)); up(upload(s, B.cull, &D.cull)); up(upload(s, B.leaf_other, &D.leaf_other));
+  up(upload(s, B.pairs, &D.pairs)); up(upload(s, B.stream, &D.leaf_stream));
   up(upload(s, root_objs, &D.root_objs)); up(upload(s, B.tri_exact, &D.tri_exact)); up(upload(s, tri_shade, &D.tri_shade));
   up(upload(s, planes, &D.planes)); up(upload(s, spheres, &D.spheres)); up(upload(s, circles, &D.circles));
   up(upload(s, types, &D.obj_type)); up(upload(s, index, &D.obj_index)); up(upload(s, omat, &D.obj_mat));
   up(upload(s, colour, &D.obj_colour)); up(upload(s, mats, &D.materials)); up(upload(s, lights, &D.lights));
   if (rc != RT_HIP_OK) { std::string m = g_err; rt_hip_scene_destroy(s); return fail(rc, m); }
-  D.n_nodes = (int32_t)B.nodes.size(); if (!d->n_nodes) D.n_nodes = 0;
+  D.root = root_ref; D.has_tree = has_tree ? 1 : 0;
   D.n_root_objs = (int32_t)root_objs.size(); D.n_objects = (int32_t)d->n_objects; D.n_lights = (int32_t)d->n_lights;
   D.ambient = d->ambient; D.coord_scale = cs;
-  s->n_nodes = (uint32_t)B.nodes.size(); s->n_leaves = B.n_leaves; s->n_cull = (uint32_t)B.cull.size(); s->max_depth = B.max_depth;
+  s->n_nodes = (uint32_t)B.pairs.size(); s->n_leaves = B.n_leaves; s->n_cull = B.n_recs; s->max_depth = B.max_depth;
   *out = s;
   return RT_HIP_OK;
 }
@@ -778,7 +805,7 @@ extern "C" int rt_hip_trace_closest_dev(rt_hip_scene *s, const rt_hip_ray *d_ray
   if (n == 0) return RT_HIP_OK;
   if (n > 0xFFFFFFFFull * 64) return fail(RT_HIP_EINVAL, "too many rays");
   HIP_TRY(hipSetDevice(s->ctx->device));
-  DevScene sc = s->dev; if (!use_tree) sc.n_nodes = 0;
+  DevScene sc = s->dev; if (!use_tree) sc.has_tree = 0;
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(s, RT_HIP_K_TRACE_CLOSEST, st);
   if (collect_stats) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, sc, d_rays, n, d_hits, s->ctx->d_stats);
@@ -811,7 +838,7 @@ extern "C" int rt_hip_trace_occluded(rt_hip_scene *s, const rt_hip_ray *rays, co
   char *base = (char *)s->staging.p;
   HIP_TRY(hipMemcpy(base, rays, rb, hipMemcpyHostToDevice));
   if (ref_pts) HIP_TRY(hipMemcpy(base + rb, ref_pts, pb, hipMemcpyHostToDevice));
-  DevScene sc = s->dev; if (!use_tree) sc.n_nodes = 0;
+  DevScene sc = s->dev; if (!use_tree) sc.has_tree = 0;
   { ProfScope ps(s, RT_HIP_K_TRACE_OCCLUDED, nullptr);
   hipLaunchKernelGGL(k_trace_occluded<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, nullptr, sc, (const rt_hip_ray *)base,
                      ref_pts ? (const double *)(base + rb) : (const double *)nullptr, n, (uint8_t *)(base + rb + pb), (Stats *)nullptr); }
@@ -889,10 +916,16 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
       if (stats) hipLaunchKernelGGL(k_trace_nodes<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, cur, n, gs);
       else hipLaunchKernelGGL(k_trace_nodes<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, cur, n, gs);
     }
+    rc = s->lum.ensure((size_t)n * std::max(1, s->dev.n_lights) * sizeof(double)); if (rc) return rc;
+    double *lum = (double *)s->lum.p;
+    if (s->dev.n_lights > 0) {
+      ProfScope ps(s, RT_HIP_K_SHADOW, st);
+      if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, (const PathNode *)cur, n, lum, cnt, gs);
+      else hipLaunchKernelGGL(k_shadow<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, (const PathNode *)cur, n, lum, cnt, gs);
+    }
     {
       ProfScope ps(s, RT_HIP_K_SHADE, st);
-      if (stats) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, next, next_cap, cnt, gs);
-      else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, next, next_cap, cnt, gs);
+      hipLaunchKernelGGL(k_shade, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt);
     }
     HIP_TRY(hipGetLastError());
     if (depth_left > 1) {
