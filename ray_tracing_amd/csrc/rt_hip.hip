@@ -300,13 +300,20 @@ __device__ __forceinline__ void stats_flush(Stats *g, const Stats &s)
   }
 }
 
-// XCD-aware block remap: consecutive hardware block ids go round-robin over the 8 XCDs (each with its
-// own L2); give every XCD one contiguous range of work items instead of a stride-8 comb.
+// XCD-aware block remap.  Consecutive hardware block ids go round-robin over the 8 XCDs (each with its
+// own L2).  Work items are handed out in chunks of RT_XCD_CHUNK consecutive blocks: chunk c goes to the
+// blocks with id % 8 == c % 8, so that one XCD's L2 serves spatially adjacent work while all XCDs walk
+// the image together (a contiguous 1/8 of the frame per XCD would tie the kernel to its most expensive
+// eighth).  The tail that does not fill 8 whole chunks keeps its identity mapping (bijective).
+#define RT_XCD_CHUNK 32
 __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int nb)
 {
-  const unsigned int q = nb / 8, r = nb % 8, x = b % 8, i = b / 8;
-  const unsigned int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-  return base + i;
+  const unsigned int group = 8u * RT_XCD_CHUNK;
+  const unsigned int full = (nb / group) * group;
+  if (b >= full) return b;
+  const unsigned int g = b / group, r = b % group;
+  const unsigned int x = r % 8, i = r / 8;            // x: which XCD's turn, i: position inside its chunk
+  return g * group + x * RT_XCD_CHUNK + i;
 }
 
 // rt_hip_trace_closest: CScene::FirstInterPt_BSPTree / FirstInterPt for a list of rays
@@ -372,12 +379,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, RenderArgs A,
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
   const unsigned int wave = xcd_remap(blockIdx.x, gridDim.x) * RT_WAVES + (threadIdx.x >> 6);
   const unsigned int lane = threadIdx.x & 63;
-  const unsigned int tiles = A.tiles_x * A.tiles_y;
-  const unsigned int s_local = wave / tiles, tile = wave % tiles;
-  const unsigned int h = (tile % A.tiles_x) * 8 + (lane & 7);
-  const unsigned int v = A.v_lo + (tile / A.tiles_x) * 8 + (lane >> 3);
+  // 8x8-pixel tile per wave; tiles are numbered super-tile by super-tile (16x8 tiles = 128x64 pixels =
+  // 128 waves = one XCD chunk of blocks), so that an XCD's L2 sees a compact 2-D patch of the image
+  const unsigned int sx = (A.tiles_x + 15) / 16, sy = (A.tiles_y + 7) / 8;
+  const unsigned int per_sample = sx * sy * 128;
+  const unsigned int s_local = wave / per_sample, wi = wave % per_sample;
+  const unsigned int st_i = wi / 128, in_st = wi % 128;
+  const unsigned int tx = (st_i % sx) * 16 + (in_st % 16), ty = (st_i / sx) * 8 + (in_st / 16);
+  const unsigned int h = tx * 8 + (lane & 7);
+  const unsigned int v = A.v_lo + ty * 8 + (lane >> 3);
   const uint64_t p = (uint64_t)v * A.cam.W + h;
-  const bool active = (s_local < A.n_samples) && (h < (unsigned)A.cam.W) && (v < (unsigned)A.cam.H) &&
+  const bool active = (s_local < A.n_samples) && (tx < A.tiles_x) && (ty < A.tiles_y) && (h < (unsigned)A.cam.W) && (v < (unsigned)A.cam.H) &&
                       (p >= A.pixel_first) && (p < A.pixel_first + A.pixel_count);
   Stats st{};
   const uint32_t sample = A.sample_first + s_local;
@@ -395,13 +407,30 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, RenderArgs A,
   if (STATS && active) st.rays++;
   traverse<false, STATS>(sc, r, active, false, mk(0, 0, 0), stack, st);
   if (active) {
-    PathNode &nd = nodes[(uint64_t)s_local * A.pixel_count + (p - A.pixel_first)];
+    PathNode &nd = nodes[(uint64_t)wave * 64 + lane];     // level 0 is stored in tile order (see node_of_pixel)
     nd.o[0] = o.x; nd.o[1] = o.y; nd.o[2] = o.z; nd.d[0] = d.x; nd.d[1] = d.y; nd.d[2] = d.z;
     nd.t = r.best_t; nd.weight = 1.0; nd.id = r.best_id;
     nd.pixel = (uint32_t)p; nd.sample = sample; nd.path = 1;
     nd.child_refr = -1; nd.child_refl = -1; nd.w_refr = 0; nd.w_refl = 0;
   }
+  else {
+    PathNode &nd = nodes[(uint64_t)wave * 64 + lane];     // padding lane of an edge tile: a miss nobody reads
+    nd.id = -1; nd.t = kMiss; nd.weight = 0; nd.pixel = 0; nd.sample = 0; nd.path = 1;
+    nd.child_refr = -1; nd.child_refl = -1; nd.w_refr = 0; nd.w_refl = 0;
+    for (int k = 0; k < 3; k++) { nd.o[k] = 0; nd.d[k] = (k == 0); }
+  }
   if (STATS) stats_flush(gstats, st);
+}
+
+// index of the level-0 node of raster pixel p (inverse of k_primary's tile numbering)
+__device__ __forceinline__ uint64_t node_of_pixel(const RenderArgs &A, uint64_t p, uint32_t s_local)
+{
+  const unsigned int h = (unsigned int)(p % A.cam.W), v = (unsigned int)(p / A.cam.W) - A.v_lo;
+  const unsigned int tx = h / 8, ty = v / 8;
+  const unsigned int sx = (A.tiles_x + 15) / 16, sy = (A.tiles_y + 7) / 8;
+  const unsigned int st_i = (ty / 8) * sx + tx / 16, in_st = (ty % 8) * 16 + (tx % 16);
+  const uint64_t wave = (uint64_t)s_local * (sx * sy * 128) + (uint64_t)st_i * 128 + in_st;
+  return wave * 64 + (v % 8) * 8 + (h % 8);
 }
 
 // levels >= 1: closest hit for queued secondary rays
@@ -430,7 +459,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DevScene sc, RenderArgs A, 
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
-  const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+  const unsigned int i = xcd_remap(blockIdx.x, gridDim.x) * RT_BLOCK + threadIdx.x;
   const bool in_range = i < n;
   Stats st{};
   int id = -1; double t = kMiss; V3 o = mk(0, 0, 0), d = mk(1, 0, 0);
@@ -552,14 +581,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(const PathNode *nodes, Ren
   const uint64_t q = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
   if (q >= A.pixel_count) return;
   if (!A.focusing) {
-    const PathNode &w = nodes[q];
+    const PathNode &w = nodes[node_of_pixel(A, A.pixel_first + q, 0)];
     rgb[3 * q] = w.col[0]; rgb[3 * q + 1] = w.col[1]; rgb[3 * q + 2] = w.col[2];
     if (prim_id) prim_id[q] = w.id;
     return;
   }
   double r = accumulate ? rgb[3 * q] : 0.0, g = accumulate ? rgb[3 * q + 1] : 0.0, b = accumulate ? rgb[3 * q + 2] : 0.0;
   for (uint32_t s = 0; s < A.n_samples; s++) {
-    const PathNode &w = nodes[(uint64_t)s * A.pixel_count + q];
+    const PathNode &w = nodes[node_of_pixel(A, A.pixel_first + q, s)];
     Col c = cdiv(mkc(w.col[0], w.col[1], w.col[2]), spp);   // RayTracer(...) / sampleTimes
     r += c.r; g += c.g; b += c.b;
   }
@@ -877,14 +906,14 @@ extern "C" int rt_hip_camera_size(const rt_hip_camera *cam, int *w, int *h)
 // the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
 static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st)
 {
-  const uint64_t n0 = A.pixel_count * A.n_samples;
-  if (n0 == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
+  const uint64_t n_waves = (uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * A.n_samples;
+  const uint64_t n0 = n_waves * 64;      // level 0 in tile order, edge tiles padded
+  if (A.pixel_count == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
   int rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
   rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
   RenderCounters *cnt = (RenderCounters *)s->counter.p;
   Stats *gs = stats ? s->ctx->d_stats : nullptr;
-  const unsigned int waves = A.tiles_x * A.tiles_y * A.n_samples;
-  const unsigned int pblocks = (waves + RT_WAVES - 1) / RT_WAVES;
+  const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
   PathNode *L0 = (PathNode *)s->levels[0].p;
   {
     ProfScope ps(s, RT_HIP_K_PRIMARY, st);
@@ -941,7 +970,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
                        (const PathNode *)s->levels[lv + 1].p, A);
     HIP_TRY(hipGetLastError());
   }
-  uint64_t rays = 0; for (int lv = 0; lv <= last; lv++) rays += n_level[lv];
+  uint64_t rays = A.pixel_count * A.n_samples; for (int lv = 1; lv <= last; lv++) rays += n_level[lv];
   s->last_rays += rays;
   return RT_HIP_OK;
 }
@@ -996,7 +1025,7 @@ extern "C" int rt_hip_render_focusing_dev(rt_hip_scene *s, const rt_hip_camera *
   HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
   s->last_rays = 0; s->last_shadow = 0;
   // batch the samples so that one level-0 array stays near 1 GiB
-  uint64_t per = (1ull << 30) / (A.pixel_count * sizeof(PathNode));
+  uint64_t per = (1ull << 30) / ((uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * 64 * sizeof(PathNode));
   uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per, 64));
   for (uint32_t done = 0; done < s_count; done += batch) {
     A.sample_first = s_first + done; A.n_samples = std::min(batch, s_count - done);
