@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=int, default=708, help="heightfield cells per side (708 -> 1,002,528 triangles)")
-    ap.add_argument("--leaf-refine", type=int, default=int(os.environ.get("RT_LEAF_REFINE", "0")))
+    ap.add_argument("--leaf-refine", type=int, default=None, help="library leaf refinement (default: library default, 32)")
     ap.add_argument("--mode", choices=["frames", "samples"], default="frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
@@ -170,8 +170,8 @@ def main():
     nodes_per_ray = st["node_visits"] / nrays
     prims_per_ray = st["prim_tests"] / nrays
     exact_per_ray = st["exact_tests"] / nrays
-    # algorithmic bytes per ray of THIS layout: ray in 48 + hit out 32 + 64 B per node visit + 128 B per cull
-    # record + 96 B per confirmed triangle (DESIGN.md "Roofline")
+    # algorithmic bytes per ray of THIS layout: ray in 48 + hit out 32 + 64 B per box test (half a 128-B child
+    # pair, or a leaf header) + 128 B per cull record + 96 B per confirmed triangle (DESIGN.md "Roofline")
     bytes_per_ray = 48 + 32 + 64 * nodes_per_ray + 128 * prims_per_ray + 96 * exact_per_ray
     flops_per_ray = 40 * nodes_per_ray + 45 * prims_per_ray + 150 * exact_per_ray
     rays_dom = (rays_per_frame - shadow_pf.value) if dom == "k_primary" else shadow_pf.value if dom == "k_shade" else rays_per_frame
@@ -222,7 +222,7 @@ def main():
            "config": {"workload": "C2: synthetic %d-triangle heightfield + ground plane, primary+shadow ray casting %dx%d, 1 frame per GPU per step"
                                   % (n_tris, W, H), "triangles": n_tris, "resolution": [W, H], "rays_per_frame": int(rays_per_frame),
                       "shadow_rays_per_frame": int(shadow_pf.value), "parallelism": "%s x%d" % (args.mode, world),
-                      "leaf_refine": args.leaf_refine, "scene_build_s": round(build_s, 2), "event_ms_per_step": round(ev_ms / args.steps, 4)},
+                      "leaf_refine": "library default (32)" if args.leaf_refine is None else args.leaf_refine, "scene_build_s": round(build_s, 2), "event_ms_per_step": round(ev_ms / args.steps, 4)},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     if world > 1:

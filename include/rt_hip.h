@@ -152,10 +152,14 @@ const char *rt_hip_last_error(void);
 int rt_hip_get_stats(rt_hip_ctx *ctx, rt_hip_stats *out, int reset);
 
 /* ---- scene: replaces CScene::ConstructBSPTree's product (Scene.h:286-293) ----------- */
-/* Copies the description to the device (replicated per GPU) and derives the traversal
- * layout.  leaf_refine > 0 lets the library split the reference's leaves further (same
- * spatial-median rule, BSPTree.h:58-109) down to that many objects -- an acceleration
- * detail that does not change any result; 0 keeps the reference tree as is. */
+/* Copies the description to the device (replicated per GPU) and derives the traversal layout.
+ * leaf_refine lets the library split the reference's leaves (< 100 objects, BSPTree.h:56-60) further
+ * with the same spatial-median rule (BSPTree.h:58-109) down to fewer than that many objects -- an
+ * acceleration detail that cannot change any result (every hit is confirmed with the reference's own
+ * arithmetic).  RT_HIP_LEAF_REFINE_DEFAULT picks the library's tuned value (32),
+ * RT_HIP_LEAF_REFINE_NONE keeps the reference's leaves as they are. */
+#define RT_HIP_LEAF_REFINE_DEFAULT 0u
+#define RT_HIP_LEAF_REFINE_NONE    0xFFFFFFFFu
 int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *desc, uint32_t leaf_refine, rt_hip_scene **out);
 int rt_hip_scene_destroy(rt_hip_scene *scene);
 

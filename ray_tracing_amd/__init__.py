@@ -23,7 +23,7 @@ def _load(name):
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
-hip = _load("librt_hip.so")     # the C ABI (include/rt_hip.h)
+hip = _load(os.environ.get("RT_HIP_LIB", "librt_hip.so"))     # the C ABI (include/rt_hip.h)
 host = _load("librt_host.so")   # C++ host layer, flat entry points (host/rt_host_capi.cpp)
 
 d3 = C.c_double * 3
@@ -175,7 +175,10 @@ class Context:
     def stats(self, reset=True):
         s = Stats()
         check(hip.rt_hip_get_stats(self.raw, C.byref(s), 1 if reset else 0))
-        return {n: getattr(s, n) for n, _ in Stats._fields_ if n != "reserved"}
+        d = {n: getattr(s, n) for n, _ in Stats._fields_ if n != "reserved"}
+        d["redo_rays"] = s.reserved & 0xFFFFFFFF     # rays re-walked with inline confirmation
+        d["redo_waves"] = s.reserved >> 32
+        return d
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -18,6 +18,10 @@
 #pragma once
 #include "rt_math.hpp"
 
+#ifndef RT_OBJ_INLINE
+#define RT_OBJ_INLINE __forceinline__   /* noinline was tried: the call ABI costs more registers than it saves */
+#endif
+
 namespace rt {
 
 // ---- device scene ------------------------------------------------------------------------------
@@ -34,29 +38,29 @@ struct alignas(128) DPair {
   int32_t axis, pad[3];
 };
 
-// Leaf stream: a 64-byte header followed by `count` 192-byte records, contiguous, so that a wave can
+// Leaf stream: a 64-byte header followed by `count` 128-byte records, contiguous, so that a wave can
 // pull a leaf into LDS with 16-byte-per-lane direct-to-LDS loads (1 KiB per instruction).
 struct alignas(64) LeafHeader { double bmin[3], bmax[3]; int32_t count, pad[3]; };
 
-// One object reference of a leaf (a triangle referenced by k leaves is stored k times).
-//   cull part   : n (= m_norm), dpl = dot(v0,n)  -> t' = (dpl - o.n)/(d.n)
-//                 B,b0 / G,g0 : beta' = dot(P',B)+b0, gamma' = dot(P',G)+g0 (dual basis of v1-v0, v2-v0)
-//                 bsum = |B|_1 + |G|_1 + 1/sin(angle at v0): scales the per-ray barycentric margin
-//   confirm part: v0, v1, v2 for the reference's own arithmetic (Object.h:416-446)
-//   kind        : 0 triangle, 1 triangle that always goes to the confirm step (degenerate / sliver),
-//                 2 any other object type (sphere ...): exact test through object_t()
+// One object reference of a leaf, 128 B (a triangle referenced by k leaves is stored k times).
+//   n (= m_norm), dpl = dot(v0,n)  -> t' = (dpl - o.n)/(d.n)
+//   B,b0 / G,g0 : beta' = dot(P',B)+b0, gamma' = dot(P',G)+g0 (dual basis of v1-v0, v2-v0)
+//   bsum = |B|_1 + |G|_1 + 1/sin(angle at v0): scales the per-ray barycentric margin
+//   kind : 0 triangle, 1 triangle whose cull data are unusable (degenerate / sliver): always confirmed,
+//          2 any other finite object type (sphere ...): exact test only
+//   tri_idx : index into tri_exact[] (raw vertices for the confirm step)
 struct alignas(64) LeafRec {
   double n[3], dpl;
   double B[3], b0;
   double G[3], g0;
   double bsum;
   int32_t prim_id, kind;
-  double v0[3], v1[3], v2[3];
-  double pad;
+  int32_t tri_idx, pad0;
+  double pad1;
 };
-static_assert(sizeof(DPair) == 128 && sizeof(LeafHeader) == 64 && sizeof(LeafRec) == 192, "layout");
+static_assert(sizeof(DPair) == 128 && sizeof(LeafHeader) == 64 && sizeof(LeafRec) == 128, "layout");
 
-#define RT_CHUNK_RECS 21                 // 64 + 21*192 = 4096 bytes of LDS per wave
+#define RT_CHUNK_RECS 31                 // 64 + 31*128 = 4032 bytes, staged as 4 x 1 KiB
 #define RT_CHUNK_BYTES 4096
 
 struct TriExact { double v0[3], v1[3], v2[3], nrm[3]; };               // 96 B, by triangle index (brute force / shading)
@@ -79,6 +83,7 @@ struct DevScene {
   const DLight *lights; int32_t n_lights;
   double ambient;
   double coord_scale;                           // max |coordinate| of finite geometry
+  double rbmin[3], rbmax[3];                    // root box (inflated); only used to order work, never for results
 };
 
 struct Stats { unsigned long long rays, shadow_rays, node_visits, prim_tests, exact_tests, wave_nodes, wave_prims, pad; };
@@ -98,7 +103,7 @@ struct WaveLds {
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---- per-object exact test (CBaseObject::FirstInterPt dispatch, Object.h:37) --------------------
-__device__ __forceinline__ double object_t(const DevScene &sc, int id, V3 o, V3 d)
+__device__ RT_OBJ_INLINE double object_t(const DevScene &sc, int id, V3 o, V3 d)
 {
   const int type = sc.obj_type[id];
   const uint32_t k = sc.obj_index[id];
@@ -132,28 +137,38 @@ __device__ __forceinline__ bool occludes(V3 o, V3 d, double t, bool has_ref, V3 
 struct RayState {
   V3 o, d;
   V3 inv;             // 1/d per axis, +-1e30 for a (near) zero component so that the slab products stay finite
-  double best_t;      // closest accepted t so far (kMiss = none); for ANY mode: upper bound of interest
+  double bound;       // prune bound: nothing beyond this t can change the result
+  double best_t;      // closest CONFIRMED t so far (kMiss = none)
   int best_id;
   double tmargin;     // per-ray t margin of the cull
   double mscale;      // per-ray scale of the barycentric margin
-  double gmin;        // per-ray |d.n| threshold
+  double gmin;        // per-ray |d.n| threshold below which the cull is not trusted
+  double tlow;        // scale of the margin of the t > eps test: tlow / |d.n|
 };
 
 __device__ __forceinline__ double safe_inv(double x) { return (fabs(x) < 1e-30) ? ((x < 0) ? -1e30 : 1e30) : 1.0 / x; }
 
+// Margins of the cull (DESIGN.md "cull margins"): with s = 1 + max|scene coordinate| + max|origin coordinate|,
+// the cull's t' differs from the exact t by at most ~7e-10 s when |d.n| >= 1e-6 (rounding of dpl - o.n,
+// about 3 ulp of s, divided by |d.n|), the point P' by the same amount, beta'/gamma' by that times |B|,|G|.
+// tmargin = 1e-6 s and mscale = 1e-8 s are > 10x those bounds; they also cover the reference's own rounding
+// noise in beta/gamma (~5e-11 |S| |B| / |d.n|).
 __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_scale)
 {
   r.o = o; r.d = d;
   r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-  r.best_t = kMiss; r.best_id = -1;
+  r.bound = kMiss; r.best_t = kMiss; r.best_id = -1;
   double os = dmax(dmax(fabs(o.x), fabs(o.y)), fabs(o.z));
   double s = 1.0 + coord_scale + os;
   r.tmargin = 1e-6 * s;
-  r.mscale = 1e-9 * s;
-  r.gmin = dmax(kGMin, 1e-7 * s);
+  r.mscale = 1e-8 * s;
+  r.gmin = 1e-6;
+  // near t = 0 (rays that start on a surface) the error of t' is the rounding of dpl - o.n (a few ulp of s)
+  // over |d.n|: 16 ulp(s) / |d.n| bounds it, and keeps a ray's own triangle (t' ~ 1e-15) out of the survivors
+  r.tlow = 16.0 * 2.3e-16 * s;
 }
 
-// branch-free slab test against an (inflated) box: does the ray overlap it for some t in (0, best_t]?
+// branch-free slab test against an (inflated) box: does the ray overlap it for some t in (0, bound]?
 __device__ __forceinline__ bool slab(const RayState &r, const double *bmin, const double *bmax)
 {
   double t1 = (bmin[0] - r.o.x) * r.inv.x, t2 = (bmax[0] - r.o.x) * r.inv.x;
@@ -162,7 +177,7 @@ __device__ __forceinline__ bool slab(const RayState &r, const double *bmin, cons
   tmin = fmax(tmin, fmin(t1, t2)); tmax = fmin(tmax, fmax(t1, t2));
   t1 = (bmin[2] - r.o.z) * r.inv.z; t2 = (bmax[2] - r.o.z) * r.inv.z;
   tmin = fmax(tmin, fmin(t1, t2)); tmax = fmin(tmax, fmax(t1, t2));
-  return (tmin <= tmax) && (tmax > 0.0) && (tmin <= r.best_t);
+  return (tmin <= tmax) && (tmax > 0.0) && (tmin <= r.bound);
 }
 
 // direct-to-LDS copy of `bytes` (rounded up to 1 KiB pieces, at most RT_CHUNK_BYTES) from a 16-byte
@@ -180,129 +195,258 @@ __device__ __forceinline__ void stage_chunk(const unsigned char *src, unsigned c
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// One staged record for all lanes of the wave; `lane_on` = lanes for which this leaf matters.
-// Returns the confirmed t (kMiss if none) for the calling lane.
-template <bool STATS>
-__device__ __forceinline__ double leaf_record(const DevScene &sc, const LeafRec &c, const RayState &r, bool lane_on,
-                                              unsigned long long &n_exact)
+// exact test of a finite non-triangle object referenced by a leaf (today: spheres)
+__device__ __forceinline__ double leaf_other_t(const DevScene &sc, int id, V3 o, V3 d)
 {
-  const int kind = uni(c.kind);
-  if (kind == 2) {                                 // sphere etc.: exact test only
-    if (STATS && lane_on) n_exact++;
-    return lane_on ? object_t(sc, uni(c.prim_id), r.o, r.d) : kMiss;
-  }
-  // ---- cull (explicit FMAs: this part only has to be conservative) ----
-  const double g = fma(r.d.z, c.n[2], fma(r.d.y, c.n[1], r.d.x * c.n[0]));
-  const double on = fma(r.o.z, c.n[2], fma(r.o.y, c.n[1], r.o.x * c.n[0]));
-  const double sn = c.dpl - on;
-  double rg = __builtin_amdgcn_rcp(g);
-  rg = fma(fma(-g, rg, 1.0), rg, rg);              // one Newton step: ~2^-50 relative
-  const double tc = sn * rg;
-  const double px = fma(r.d.x, tc, r.o.x), py = fma(r.d.y, tc, r.o.y), pz = fma(r.d.z, tc, r.o.z);
-  const double be = fma(pz, c.B[2], fma(py, c.B[1], fma(px, c.B[0], c.b0)));
-  const double ga = fma(pz, c.G[2], fma(py, c.G[1], fma(px, c.G[0], c.g0)));
-  const double m = fma(r.mscale, c.bsum, 1e-6);
-  const bool small_g = !(fabs(g) >= r.gmin) || (kind == 1);   // also catches NaN
-  const bool inside = (tc > -r.tmargin) && (tc < r.best_t + r.tmargin) && (be > -m) && (ga > -m) && (be + ga < 1.0 + m);
-  const bool pass = lane_on && (small_g || inside);
-  double t = kMiss;
-  if (pass) {
-    // ---- confirm: the reference's arithmetic on the raw vertices ----
-    if (STATS) n_exact++;
-    t = tri_exact_t(mk(c.v0[0], c.v0[1], c.v0[2]), mk(c.v1[0], c.v1[1], c.v1[2]), mk(c.v2[0], c.v2[1], c.v2[2]),
-                    mk(c.n[0], c.n[1], c.n[2]), r.o, r.d);
-  }
-  return t;
+  const DSphere &S = sc.spheres[sc.obj_index[id]];
+  return sphere_t(mk(S.c[0], S.c[1], S.c[2]), S.r, o, d);
 }
 
-// Packet traversal.  ANY = false: closest hit into r.best_t / r.best_id (Scene.h:85-91 semantics).
-// ANY = true: returns true for a lane as soon as some hit satisfies occludes(); r.best_t must be
-// preset to the largest t of interest (kMiss if unbounded).
-// `lds` is this wave's WaveLds.  All lanes of the wave must call this together (inactive rays pass
-// active = false).
-template <bool ANY, bool STATS>
-__device__ __forceinline__ bool traverse(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref,
-                                         WaveLds *lds, Stats &st)
+// confirm step by primitive id: the reference's arithmetic on the raw vertices (per-lane gather)
+__device__ RT_OBJ_INLINE double confirm_triangle(const DevScene &sc, int prim, V3 o, V3 d)
 {
-  bool found = false;        // ANY mode result
-  // update rule shared by every candidate (Scene.h:74-79): first candidate wins ties within eps
-  auto candidate = [&](double t, int id, bool lane_on) {
+  const TriExact &T = sc.tri_exact[sc.obj_index[prim]];
+  return tri_exact_t(mk(T.v0[0], T.v0[1], T.v0[2]), mk(T.v1[0], T.v1[1], T.v1[2]), mk(T.v2[0], T.v2[1], T.v2[2]),
+                     mk(T.nrm[0], T.nrm[1], T.nrm[2]), o, d);
+}
+
+// Deferred-confirmation state of one ray.  During the fast walk only the cull runs; the two nearest
+// cull survivors (by t') are remembered and confirmed once, after the walk, by all lanes together.
+// A lane whose survivors are not conclusive (see finish_closest / finish_any) is re-walked with the
+// confirm step inline (walk<.., false>), so the result never depends on the cull's approximations.
+struct Deferred {
+  double c1_t, c2_t, c3_t;   // t' of the nearest, second nearest and nearest discarded survivor
+  int c1_id, c2_id;
+  bool redo;                 // met something the fast walk cannot judge (|d.n| tiny, degenerate triangle)
+};
+
+// One tree walk.  DEFER = true: fast walk (cull only, survivors into D).  DEFER = false: every cull survivor
+// is confirmed inline with the reference's arithmetic.
+// ANY = false: closest hit; confirmed hits go to r.best_t / r.best_id, r.bound prunes.
+// ANY = true : occlusion; `found` becomes true for a lane as soon as a confirmed hit satisfies occludes()
+//              (DEFER: as soon as a cull survivor MAY satisfy it; D.c1_id remembers which).
+template <bool ANY, bool DEFER, bool STATS>
+__device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref, double fmargin,
+                                     WaveLds *lds, Stats &st, Deferred &D, bool &found)
+{
+  // confirmed candidate (Scene.h:74-79): first candidate wins ties within eps
+  auto confirmed = [&](double t, int id, bool lane_on) {
     if (!lane_on || !(t < kMiss)) return;
     if (ANY) {
       if (occludes(r.o, r.d, t, has_ref, ref)) found = true;
     } else {
-      if (r.best_id < 0 || t < r.best_t - kEps) { r.best_t = t; r.best_id = id; }
-    }
-  };
-
-  if (sc.has_tree) {
-    int sp = 0;
-    lds->stack[0] = sc.root; sp = 1;
-    while (sp > 0) {
-      --sp;
-      const int i0 = uni(lds->stack[sp].i0), i1 = uni(lds->stack[sp].i1);
-      const bool live = active && !(ANY && found);
-      if (__ballot(live) == 0ull) break;            // every ray of the wave is finished
-      if (i0 >= 0) {
-        // ---- inner node: fetch both child boxes at once, keep the children some lane wants ----
-        const DPair &P = sc.pairs[i0];
-        const bool wl = live && slab(r, P.lmin, P.lmax);
-        const bool wr = live && slab(r, P.rmin, P.rmax);
-        if (STATS) { if (live) st.node_visits += 2; if ((threadIdx.x & 63) == 0) st.wave_nodes += 2; }
-        const unsigned long long ml = __ballot(wl), mr = __ballot(wr);
-        const int axis = uni(P.axis);
-        const double da = (axis == 0) ? r.d.x : ((axis == 1) ? r.d.y : r.d.z);
-        const unsigned long long pos = __ballot((wl || wr) && (da >= 0.0));
-        const bool left_first = (2 * __popcll(pos) >= __popcll(ml | mr));
-        const ChildRef L = P.l, R = P.r;
-        // push far first so that the near child is popped next
-        if (left_first) { if (mr) lds->stack[sp++] = R; if (ml) lds->stack[sp++] = L; }
-        else            { if (ml) lds->stack[sp++] = L; if (mr) lds->stack[sp++] = R; }
-      } else {
-        // ---- leaf: stage header + records in LDS chunk by chunk ----
-        const int cnt = -1 - i0;
-        const unsigned char *base = sc.leaf_stream + (size_t)(unsigned)i1 * 64;
-        bool want = false;
-        for (int c0 = 0; c0 < cnt; c0 += RT_CHUNK_RECS) {
-          const int nrec = (cnt - c0 < RT_CHUNK_RECS) ? (cnt - c0) : RT_CHUNK_RECS;
-          stage_chunk(base + (size_t)c0 * sizeof(LeafRec), lds->leaf, 64 + nrec * (int)sizeof(LeafRec));
-          if (c0 == 0) {
-            const LeafHeader *H = (const LeafHeader *)lds->leaf;
-            want = live && slab(r, H->bmin, H->bmax);
-            if (STATS) { if (live) st.node_visits++; if ((threadIdx.x & 63) == 0) st.wave_nodes++; }
-            if (__ballot(want) == 0ull) break;
-          }
-          const LeafRec *recs = (const LeafRec *)(lds->leaf + 64);
-          for (int i = 0; i < nrec; i++) {
-            const LeafRec &c = recs[i];
-            const bool lane_on = want && !(ANY && found);
-            if (STATS) { if (lane_on) st.prim_tests++; if ((threadIdx.x & 63) == 0) st.wave_prims++; }
-            double t = leaf_record<STATS>(sc, c, r, lane_on, st.exact_tests);
-            candidate(t, uni(c.prim_id), lane_on);
-          }
-          // the next chunk overwrites the LDS image: all reads above are complete (values consumed)
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+      // within a leaf the reference keeps the first-listed (= lower id) of two hits closer than eps (Scene.h:74-79);
+      // the walk order here differs from the reference's, so the lower id is made to win explicitly
+      if (r.best_id < 0 || t < r.best_t - kEps || (t <= r.best_t + kEps && id < r.best_id)) {
+        r.best_t = t; r.best_id = id; r.bound = fmin(r.bound, t + r.tmargin);
       }
     }
-    // root's infinite objects (Scene.h:329-346, 369-386), once per ray
-    for (int i = 0; i < sc.n_root_objs; i++) {
-      const int id = uni(sc.root_objs[i]);
-      const bool lane_on = active && !(ANY && found);
-      double t = lane_on ? object_t(sc, id, r.o, r.d) : kMiss;
-      if (STATS && lane_on) st.exact_tests++;
-      candidate(t, id, lane_on);
-    }
-  } else {
-    // no tree: CScene::FirstInterPt (Scene.h:62-83) -- every object, in order
-    for (int id = 0; id < sc.n_objects; id++) {
-      const bool lane_on = active && !(ANY && found);
-      if (ANY && __ballot(lane_on) == 0ull) break;
-      double t = lane_on ? object_t(sc, id, r.o, r.d) : kMiss;
-      if (STATS && lane_on) st.exact_tests++;
-      candidate(t, id, lane_on);
+  };
+  int sp = 0;
+  lds->stack[0] = sc.root; sp = 1;
+  while (sp > 0) {
+    --sp;
+    const int i0 = uni(lds->stack[sp].i0), i1 = uni(lds->stack[sp].i1);
+    const bool live = active && !(ANY && found);
+    if (__ballot(live) == 0ull) break;            // every ray of the wave is finished
+    if (i0 >= 0) {
+      // ---- inner node: fetch both child boxes at once, keep the children some lane wants ----
+      const DPair &P = sc.pairs[i0];
+      const bool wl = live && slab(r, P.lmin, P.lmax);
+      const bool wr = live && slab(r, P.rmin, P.rmax);
+      if (STATS) { if (live) st.node_visits += 2; if ((threadIdx.x & 63) == 0) st.wave_nodes += 2; }
+      const unsigned long long ml = __ballot(wl), mr = __ballot(wr);
+      const int axis = uni(P.axis);
+      const double da = (axis == 0) ? r.d.x : ((axis == 1) ? r.d.y : r.d.z);
+      const unsigned long long pos = __ballot((wl || wr) && (da >= 0.0));
+      const bool left_first = (2 * __popcll(pos) >= __popcll(ml | mr));
+      const ChildRef L = P.l, R = P.r;
+      // push far first so that the near child is popped next
+      if (left_first) { if (mr) lds->stack[sp++] = R; if (ml) lds->stack[sp++] = L; }
+      else            { if (ml) lds->stack[sp++] = L; if (mr) lds->stack[sp++] = R; }
+    } else {
+      // ---- leaf: stage header + records in LDS chunk by chunk ----
+      const int cnt = -1 - i0;
+      const unsigned char *base = sc.leaf_stream + (size_t)(unsigned)i1 * 64;
+      bool want = false;
+      for (int c0 = 0; c0 < cnt; c0 += RT_CHUNK_RECS) {
+        const int nrec = (cnt - c0 < RT_CHUNK_RECS) ? (cnt - c0) : RT_CHUNK_RECS;
+        stage_chunk(base + (size_t)c0 * sizeof(LeafRec), lds->leaf, 64 + nrec * (int)sizeof(LeafRec));
+        if (c0 == 0) {
+          const LeafHeader *H = (const LeafHeader *)lds->leaf;
+          want = live && slab(r, H->bmin, H->bmax);
+          if (STATS) { if (live) st.node_visits++; if ((threadIdx.x & 63) == 0) st.wave_nodes++; }
+          if (__ballot(want) == 0ull) break;
+        }
+        const LeafRec *recs = (const LeafRec *)(lds->leaf + 64);
+#ifdef RT_UNROLL
+#pragma unroll RT_UNROLL
+#endif
+        for (int i = 0; i < nrec; i++) {
+          const LeafRec &c = recs[i];
+          const bool lane_on = want && !(ANY && found);
+          if (STATS) { if (lane_on) st.prim_tests++; if ((threadIdx.x & 63) == 0) st.wave_prims++; }
+          // all cull fields in one batch of LDS reads (no short-circuit: each would cost another round trip)
+          const double n0 = c.n[0], n1 = c.n[1], n2 = c.n[2], dpl = c.dpl;
+          const double B0 = c.B[0], B1 = c.B[1], B2 = c.B[2], b0 = c.b0;
+          const double G0 = c.G[0], G1 = c.G[1], G2 = c.G[2], g0 = c.g0;
+          const double bsum = c.bsum;
+          const int kind = uni(c.kind), prim = uni(c.prim_id);     // same LDS batch as the cull fields
+          // ---- cull (explicit FMAs: this part only has to be conservative) ----
+          const double g = fma(r.d.z, n2, fma(r.d.y, n1, r.d.x * n0));
+          const double on = fma(r.o.z, n2, fma(r.o.y, n1, r.o.x * n0));
+          double rg = __builtin_amdgcn_rcp(g);
+          rg = fma(fma(-g, rg, 1.0), rg, rg);       // one Newton step: ~2^-50 relative
+          const double tc = (dpl - on) * rg;
+          const double px = fma(r.d.x, tc, r.o.x), py = fma(r.d.y, tc, r.o.y), pz = fma(r.d.z, tc, r.o.z);
+          const double be = fma(pz, B2, fma(py, B1, fma(px, B0, b0)));
+          const double ga = fma(pz, G2, fma(py, G1, fma(px, G0, g0)));
+          const double m = fma(r.mscale, bsum, 1e-6);
+          const bool untrusted = !(fabs(g) >= r.gmin) | (kind == 1);      // also catches NaN
+          const bool inside = (tc > kEps - r.tlow * fabs(rg)) & (tc < r.bound + r.tmargin) & (be > -m) & (ga > -m) & (be + ga < 1.0 + m);
+          if (kind == 2) {                          // sphere etc.: exact test only (wave-uniform, rare)
+            if (STATS && lane_on) st.exact_tests++;
+            confirmed(lane_on ? leaf_other_t(sc, prim, r.o, r.d) : kMiss, prim, lane_on);
+          } else if (DEFER) {
+            if (lane_on & untrusted) D.redo = true;
+            if (lane_on & inside & !untrusted) {
+              if (ANY) {
+                // may this survivor occlude?  f(t) = Dot(o - X, ref - X), X = o + d t (Scene.h:449)
+                bool maybe = true;
+                if (has_ref) { V3 X = mk(px, py, pz); maybe = dot(r.o - X, ref - X) < -kEps + fmargin; }
+                if (maybe) { found = true; D.c1_id = prim; D.c1_t = tc; }
+              } else if (prim != D.c1_id && prim != D.c2_id) {
+                if (tc < D.c1_t) { D.c3_t = fmin(D.c3_t, D.c2_t); D.c2_t = D.c1_t; D.c2_id = D.c1_id; D.c1_t = tc; D.c1_id = prim; }
+                else if (tc < D.c2_t) { D.c3_t = fmin(D.c3_t, D.c2_t); D.c2_t = tc; D.c2_id = prim; }
+                else D.c3_t = fmin(D.c3_t, tc);
+                r.bound = fmin(r.bound, D.c1_t + 2.0 * r.tmargin);
+              }
+            }
+          } else {
+            const bool pass = lane_on & (untrusted | inside);
+            if (pass) {
+              if (STATS) st.exact_tests++;
+              const TriExact &T = sc.tri_exact[uni(c.tri_idx)];
+              double t = tri_exact_t(mk(T.v0[0], T.v0[1], T.v0[2]), mk(T.v1[0], T.v1[1], T.v1[2]), mk(T.v2[0], T.v2[1], T.v2[2]),
+                                     mk(n0, n1, n2), r.o, r.d);
+              confirmed(t, prim, true);
+            }
+          }
+        }
+        // the next chunk overwrites the LDS image: all reads above are complete (values consumed)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     }
   }
+}
+
+// Closest hit of one ray per lane (CScene::FirstInterPt_BSPTree, Scene.h:85-91; FirstInterPt, Scene.h:62-83,
+// when the scene has no tree).  Result in r.best_t / r.best_id.  All lanes of the wave call this together.
+template <bool STATS>
+__device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, bool active, WaveLds *lds, Stats &st)
+{
+  auto take = [&](double t, int id) {          // the update rule of Scene.h:74-79 (objects come in id order)
+    if (t < kMiss && (r.best_id < 0 || t < r.best_t - kEps)) { r.best_t = t; r.best_id = id; }
+  };
+  if (!sc.has_tree) {
+    for (int id = 0; id < sc.n_objects; id++) {
+      double t = active ? object_t(sc, id, r.o, r.d) : kMiss;
+      if (STATS && active) st.exact_tests++;
+      if (active) take(t, id);
+    }
+    return;
+  }
+  // root's infinite objects (Scene.h:329-346, 369-386) first: their hit bounds the walk.  They are applied
+  // AFTER the finite objects below, as in the reference's leaf loop, so that finite objects win ties.
+  double inf_t = kMiss; int inf_id = -1;
+  for (int i = 0; i < sc.n_root_objs; i++) {
+    const int id = uni(sc.root_objs[i]);
+    double t = active ? object_t(sc, id, r.o, r.d) : kMiss;
+    if (STATS && active) st.exact_tests++;
+    if (t < kMiss && (inf_id < 0 || t < inf_t - kEps)) { inf_t = t; inf_id = id; }
+  }
+  if (inf_id >= 0) r.bound = inf_t + r.tmargin;
+  Deferred D; D.c1_t = D.c2_t = D.c3_t = kMiss; D.c1_id = D.c2_id = -1; D.redo = false;
+  bool dummy = false;
+  walk<false, true, STATS>(sc, r, active, false, mk(0, 0, 0), 0.0, lds, st, D, dummy);
+  // ---- confirm the survivors, all lanes together ----
+  const bool h1 = active && D.c1_id >= 0, h2 = active && D.c2_id >= 0;
+  double t1 = kMiss, t2 = kMiss;
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) {
+    const bool hk = k ? h2 : h1;
+    const int idk = k ? D.c2_id : D.c1_id;
+    double tk = hk ? confirm_triangle(sc, idk, r.o, r.d) : kMiss;
+    if (k) t2 = tk; else t1 = tk;
+  }
+  if (STATS) st.exact_tests += (h1 ? 1 : 0) + (h2 ? 1 : 0);
+  // not conclusive: the nearest survivor was not a hit after all, or a third one is as near as the first
+  bool redo = active && (D.redo || (h1 && !(t1 < kMiss)) || (D.c3_t < kMiss && D.c3_t <= D.c1_t + 4.0 * r.tmargin));
+#ifndef RT_NO_REDO
+  if (__ballot(redo) != 0ull) {
+    if (STATS) { if (redo) st.pad++; if ((threadIdx.x & 63) == 0) st.pad += (1ull << 32); }
+    RayState q = r;
+    q.best_t = kMiss; q.best_id = -1; q.bound = (inf_id >= 0) ? inf_t + r.tmargin : kMiss;
+    walk<false, false, STATS>(sc, q, redo, false, mk(0, 0, 0), 0.0, lds, st, D, dummy);
+    if (redo) { r.best_t = q.best_t; r.best_id = q.best_id; }
+  }
+#endif
+  if (active && !redo) {
+    // spheres etc. confirmed during the walk sit in r.best_*; merge the triangle survivors in object order
+    double e_t = r.best_t; int e_id = r.best_id;
+    r.best_t = kMiss; r.best_id = -1;
+    const bool first1 = !(h2 && t2 < kMiss) || D.c1_id < D.c2_id;
+    if (first1) { take(t1, D.c1_id); take(t2, D.c2_id); } else { take(t2, D.c2_id); take(t1, D.c1_id); }
+    take(e_t, e_id);
+  }
+  if (active) take(inf_t, inf_id);
+}
+
+// Occlusion query of one ray per lane: is there a hit X with occludes() true (Scene.h:449, Light.h:66,91,147)?
+// t_limit: no hit beyond it can satisfy the predicate (kMiss if unbounded).
+template <bool STATS>
+__device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref, double t_limit,
+                                               WaveLds *lds, Stats &st)
+{
+  bool found = false;
+  if (!sc.has_tree) {
+    for (int id = 0; id < sc.n_objects; id++) {
+      const bool lane_on = active && !found;
+      if (__ballot(lane_on) == 0ull) break;
+      double t = lane_on ? object_t(sc, id, r.o, r.d) : kMiss;
+      if (STATS && lane_on) st.exact_tests++;
+      if (lane_on && t < kMiss && occludes(r.o, r.d, t, has_ref, ref)) found = true;
+    }
+    return found;
+  }
+  for (int i = 0; i < sc.n_root_objs; i++) {
+    const int id = uni(sc.root_objs[i]);
+    const bool lane_on = active && !found;
+    double t = lane_on ? object_t(sc, id, r.o, r.d) : kMiss;
+    if (STATS && lane_on) st.exact_tests++;
+    if (lane_on && t < kMiss && occludes(r.o, r.d, t, has_ref, ref)) found = true;
+  }
+  r.bound = t_limit;
+  const double fmargin = 3.0 * (len(ref - r.o) + 1.0) * r.tmargin;
+  Deferred D; D.c1_t = D.c2_t = D.c3_t = kMiss; D.c1_id = D.c2_id = -1; D.redo = false;
+  const bool pre = found;
+  walk<true, true, STATS>(sc, r, active && !pre, has_ref, ref, fmargin, lds, st, D, found);
+  // ---- confirm the survivor that stopped the walk ----
+  const bool h1 = active && !pre && found && D.c1_id >= 0;
+  bool ok = false;
+  if (h1) { double t = confirm_triangle(sc, D.c1_id, r.o, r.d); ok = (t < kMiss) && occludes(r.o, r.d, t, has_ref, ref); }
+  if (STATS && h1) st.exact_tests++;
+  // (found && !h1) = a sphere confirmed inline; (!found) = nothing may occlude; both are final unless flagged
+  bool redo = active && !pre && ((h1 && !ok) || (D.redo && !(h1 && ok)));
+#ifndef RT_NO_REDO
+  if (__ballot(redo) != 0ull) {
+    if (STATS) { if (redo) st.pad++; if ((threadIdx.x & 63) == 0) st.pad += (1ull << 32); }
+    bool f2 = false;
+    RayState q = r; q.bound = t_limit;
+    walk<true, false, STATS>(sc, q, redo, has_ref, ref, fmargin, lds, st, D, f2);
+    if (redo) found = f2;
+  }
+#endif
   return found;
 }
 
@@ -386,40 +530,35 @@ struct RngKey { uint64_t seed; uint32_t pixel, sample, path; };
 
 // luminosity of one light at pt: CBaseLight::luminosity (Light.h:34-44) with the InShadow rules of
 // Light.h:62-69 / 87-94, CAreaLight::luminosity (Light.h:126-162) and luminosity_BSPTree
-// (Scene.h:436-455).  Every shadow query is a wave-packet ANY traversal.
+// (Scene.h:436-455).  Every shadow query is a wave-packet occlusion walk; point and parallel lights are
+// the one-sample case of the same loop.
 template <bool STATS>
 __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLight &L, int li, V3 pt, bool active,
-                                                   const RngKey &key, WaveLds *stack, Stats &st)
+                                                   const RngKey &key, WaveLds *lds, Stats &st)
 {
   const V3 lp = mk(L.p[0], L.p[1], L.p[2]);
   const int type = uni(L.type);
-  if (type == 100 || type == 101) {            // point / parallel
-    V3 dir = (type == 100) ? (lp - pt) : neg(lp);
-    RayState r; ray_setup(r, pt, unitize(dir), sc.coord_scale);
-    if (type == 100) r.best_t = dot(lp - pt, r.d) + 1e-6 * (1.0 + sc.coord_scale);
-    if (STATS && active) { st.rays++; st.shadow_rays++; }
-    bool occ = traverse<true, STATS>(sc, r, active, type == 100, lp, stack, st);
-    return occ ? 0.0 : L.lum;
-  }
-  // area light
-  double lum = 0;
-  const int sn = uni(L.sample_num);
-  const double rr = (L.len / double(sn)) / 2;
+  const bool area = (type == 102);
+  const int sn = area ? uni(L.sample_num) : 1;
+  const double rr = area ? (L.len / double(sn)) / 2 : 0.0;
   const V3 O = mk(lp.x - sn * rr, lp.y - sn * rr, lp.z);
-  for (int i = 0; i < sn; i++) {
-    for (int j = 0; j < sn; j++) {
+  const double per = area ? L.lum_per_sample : L.lum;
+  double lum = 0;
+  for (int s = 0; s < sn * sn; s++) {
+    const int i = s / sn, j = s % sn;
+    V3 dir;
+    if (area) {
       double x0 = O.x + i * rr * 2, y0 = O.y + j * rr * 2, z0 = O.z;
-      uint32_t ls = (uint32_t)(i * sn + j);
-      double rx = ref_random(rr, 1000, key.seed, key.pixel, key.sample, key.path, (uint32_t)li, ls, 0);
-      double ry = ref_random(rr, 1000, key.seed, key.pixel, key.sample, key.path, (uint32_t)li, ls, 1);
-      V3 sp = mk(x0 + rx, y0 + ry, z0);
-      RayState r; ray_setup(r, pt, unitize(sp - pt), sc.coord_scale);
-      // hits beyond the projection of the light centre onto the ray can never satisfy the predicate
-      r.best_t = fabs(dot(lp - pt, r.d)) + 1e-6 * (1.0 + sc.coord_scale);
-      if (STATS && active) { st.rays++; st.shadow_rays++; }
-      bool occ = traverse<true, STATS>(sc, r, active, true, lp, stack, st);
-      if (!occ) lum += L.lum_per_sample;
-    }
+      double rx = ref_random(rr, 1000, key.seed, key.pixel, key.sample, key.path, (uint32_t)li, (uint32_t)s, 0);
+      double ry = ref_random(rr, 1000, key.seed, key.pixel, key.sample, key.path, (uint32_t)li, (uint32_t)s, 1);
+      dir = mk(x0 + rx, y0 + ry, z0) - pt;
+    } else dir = (type == 100) ? (lp - pt) : neg(lp);
+    RayState r; ray_setup(r, pt, unitize(dir), sc.coord_scale);
+    // hits beyond the projection of the light position onto the ray can never satisfy the predicate
+    const double t_limit = (type == 101) ? kMiss : fabs(dot(lp - pt, r.d)) + 1e-6 * (1.0 + sc.coord_scale);
+    if (STATS && active) { st.rays++; st.shadow_rays++; }
+    bool occ = trace_occluded<STATS>(sc, r, active, type != 101, lp, t_limit, lds, st);
+    if (!occ) lum += per;
   }
   return lum;
 }

@@ -72,6 +72,7 @@ struct rt_hip_scene {
   // render workspace (grow-only, reused between calls)
   static constexpr int kMaxLevels = 16;
   DevBuf levels[kMaxLevels];
+  DevBuf order;                   // heavy-first wave order lists + flags
   DevBuf lum;                     // per node, per light luminosity (shadow pass -> shade pass)
   DevBuf counter;                 // queue counter + per-render ray counters
   DevBuf staging;                 // host-pointer entry points
@@ -145,9 +146,9 @@ struct Builder {
     LeafRec c; std::memset(&c, 0, sizeof c);
     c.prim_id = (int32_t)prim;
     if (d->obj_type[prim] != RT_HIP_TRIANGLE) { c.kind = 2; return c; }
+    c.tri_idx = (int32_t)d->obj_index[prim];
     const TriExact &T = tri_exact[d->obj_index[prim]];
-    std::memcpy(c.v0, T.v0, 24); std::memcpy(c.v1, T.v1, 24); std::memcpy(c.v2, T.v2, 24);
-    std::memcpy(c.n, T.nrm, 24);     // m_norm, needed by the confirm step in every case
+    std::memcpy(c.n, T.nrm, 24);     // m_norm, used by the confirm step in every case
     c.kind = 1;                      // until the cull data prove usable
     V3 v0 = mk(T.v0[0], T.v0[1], T.v0[2]), v1 = mk(T.v1[0], T.v1[1], T.v1[2]), v2 = mk(T.v2[0], T.v2[1], T.v2[2]);
     V3 n = mk(T.nrm[0], T.nrm[1], T.nrm[2]);
@@ -279,8 +280,27 @@ int upload(rt_hip_scene *s, const std::vector<T> &v, const T **out)
 // ================================================================================================
 // kernels
 // ================================================================================================
-#define RT_BLOCK 256
+#ifndef RT_BLOCK
+#define RT_BLOCK 64     /* one wave per workgroup: waves of very different cost pack the CUs best (measured) */
+#endif
+#ifndef RT_MINWAVES
+#define RT_MINWAVES 1   /* __launch_bounds__ second argument: minimum waves per SIMD */
+#endif
 #define RT_WAVES (RT_BLOCK / 64)
+
+// diagnostic only (collect_stats builds of the kernels): start/end wall-clock stamp of every wave
+#define RT_MAX_STAMPS 65536
+__device__ unsigned long long g_stamps[2 * RT_MAX_STAMPS];
+__device__ __forceinline__ void stamp(unsigned int wave, int which)
+{
+  if ((threadIdx.x & 63) == 0 && wave < RT_MAX_STAMPS) g_stamps[2 * wave + which] = wall_clock64();
+}
+extern "C" int rt_hip_debug_read_stamps(unsigned long long *out, size_t n_waves)
+{
+  if (n_waves > RT_MAX_STAMPS) n_waves = RT_MAX_STAMPS;
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n_waves * 16, 0, hipMemcpyDeviceToHost));
+  return RT_HIP_OK;
+}
 
 struct DevCamera {
   V3 view_pt, start, left, up;
@@ -291,9 +311,9 @@ __device__ __forceinline__ void stats_flush(Stats *g, const Stats &s)
 {
   if (!g) return;
   // per-lane counters -> one atomic per lane is too many: reduce over the wave first
-  unsigned long long v[7] = {s.rays, s.shadow_rays, s.node_visits, s.prim_tests, s.exact_tests, s.wave_nodes, s.wave_prims};
+  unsigned long long v[8] = {s.rays, s.shadow_rays, s.node_visits, s.prim_tests, s.exact_tests, s.wave_nodes, s.wave_prims, s.pad};
 #pragma unroll
-  for (int k = 0; k < 7; k++) {
+  for (int k = 0; k < 8; k++) {
     unsigned long long x = v[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
     if ((threadIdx.x & 63) == 0 && x) atomicAdd(((unsigned long long *)g) + k, x);
@@ -305,7 +325,7 @@ __device__ __forceinline__ void stats_flush(Stats *g, const Stats &s)
 // blocks with id % 8 == c % 8, so that one XCD's L2 serves spatially adjacent work while all XCDs walk
 // the image together (a contiguous 1/8 of the frame per XCD would tie the kernel to its most expensive
 // eighth).  The tail that does not fill 8 whole chunks keeps its identity mapping (bijective).
-#define RT_XCD_CHUNK 32
+#define RT_XCD_CHUNK (128 / RT_WAVES)   /* one 128-wave super-tile per XCD turn */
 __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int nb)
 {
   const unsigned int group = 8u * RT_XCD_CHUNK;
@@ -318,7 +338,7 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
 
 // rt_hip_trace_closest: CScene::FirstInterPt_BSPTree / FirstInterPt for a list of rays
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(DevScene sc, const rt_hip_ray *rays, size_t n, rt_hip_hit *hits, Stats *gstats)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_trace_closest(DevScene sc, const rt_hip_ray *rays, size_t n, rt_hip_hit *hits, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
@@ -329,7 +349,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(DevScene sc, const r
   if (active) { const rt_hip_ray q = rays[i]; o = mk(q.o[0], q.o[1], q.o[2]); d = unitize(mk(q.d[0], q.d[1], q.d[2])); }
   RayState r; ray_setup(r, o, d, sc.coord_scale);
   if (STATS && active) st.rays++;
-  traverse<false, STATS>(sc, r, active, false, mk(0, 0, 0), stack, st);
+  trace_closest<STATS>(sc, r, active, stack, st);
   if (active) {
     rt_hip_hit h; h.prim_id = r.best_id; h.reserved = 0; h.u = kInfty; h.v = kInfty;
     h.t = (r.best_id >= 0) ? r.best_t : kInfty;
@@ -339,7 +359,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(DevScene sc, const r
 }
 
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_occluded(DevScene sc, const rt_hip_ray *rays, const double *ref_pts, size_t n,
+__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_trace_occluded(DevScene sc, const rt_hip_ray *rays, const double *ref_pts, size_t n,
                                                               uint8_t *occluded, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
@@ -353,9 +373,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_occluded(DevScene sc, const 
     if (ref_pts) ref = mk(ref_pts[3 * i], ref_pts[3 * i + 1], ref_pts[3 * i + 2]);
   }
   RayState r; ray_setup(r, o, d, sc.coord_scale);
-  if (ref_pts) r.best_t = fabs(dot(ref - o, d)) + 1e-6 * (1.0 + sc.coord_scale);
+  const double t_limit = ref_pts ? fabs(dot(ref - o, d)) + 1e-6 * (1.0 + sc.coord_scale) : kMiss;
   if (STATS && active) { st.rays++; st.shadow_rays++; }
-  bool occ = traverse<true, STATS>(sc, r, active, ref_pts != nullptr, ref, stack, st);
+  bool occ = trace_occluded<STATS>(sc, r, active, ref_pts != nullptr, ref, t_limit, stack, st);
   if (active) occluded[i] = occ ? 1 : 0;
   if (STATS) stats_flush(gstats, st);
 }
@@ -371,21 +391,79 @@ struct RenderArgs {
   double lens_radius; int focusing;
 };
 
+// ---- heavy-first work order --------------------------------------------------------------------
+// Waves whose rays can meet the tree cost 10-50x more than waves that only see the infinite planes.  A
+// grid in image order leaves the expensive tiles of the lower image rows for the end, and the kernel
+// then drains at low occupancy for a third of its run time.  k_order lists the waves flagged heavy
+// first (in their original, spatially coherent order), the light ones after them.  Results do not
+// depend on the order.
+__device__ __forceinline__ bool ray_meets_box(V3 o, V3 d, const double *bmin, const double *bmax)
+{
+  RayState r; r.o = o; r.d = d; r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)); r.bound = kMiss;
+  return slab(r, bmin, bmax);
+}
+
+__device__ __forceinline__ void tile_of_wave(const RenderArgs &A, unsigned int wave, unsigned int &s_local, unsigned int &tx, unsigned int &ty)
+{
+  const unsigned int sx = (A.tiles_x + 15) / 16, sy = (A.tiles_y + 7) / 8;
+  const unsigned int per_sample = sx * sy * 128;
+  s_local = wave / per_sample;
+  const unsigned int wi = wave % per_sample, st_i = wi / 128, in_st = wi % 128;
+  tx = (st_i % sx) * 16 + (in_st % 16); ty = (st_i / sx) * 8 + (in_st / 16);
+}
+
+// one thread per wave of k_primary: heavy iff one of the tile's corner rays meets the root box
+__global__ void __launch_bounds__(256) k_classify(DevScene sc, RenderArgs A, unsigned int n_waves, unsigned char *flags)
+{
+  const unsigned int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_waves) return;
+  unsigned int s_local, tx, ty; tile_of_wave(A, w, s_local, tx, ty);
+  bool heavy = false;
+  if (tx < A.tiles_x && ty < A.tiles_y) {
+    for (int c = 0; c < 4; c++) {
+      const unsigned int h = tx * 8 + ((c & 1) ? 7 : 0), v = A.v_lo + ty * 8 + ((c & 2) ? 7 : 0);
+      V3 cur = A.cam.start - A.cam.left * (double(h) / double(A.cam.res)) - A.cam.up * (double(v) / double(A.cam.res));
+      heavy = heavy || ray_meets_box(A.cam.view_pt, unitize(cur - A.cam.view_pt), sc.rbmin, sc.rbmax);
+    }
+  }
+  flags[w] = heavy ? 1 : 0;
+}
+
+// single block: stable partition of the wave indices by flag
+__global__ void __launch_bounds__(1024) k_order(const unsigned char *flags, unsigned int n, unsigned int *order)
+{
+  __shared__ unsigned int s_cnt[1024];
+  const unsigned int t = threadIdx.x, per = (n + 1023) / 1024;
+  const unsigned int lo = min(n, t * per), hi = min(n, lo + per);
+  unsigned int c = 0;
+  for (unsigned int i = lo; i < hi; i++) c += flags[i] ? 1u : 0u;
+  s_cnt[t] = c;
+  __syncthreads();
+  for (unsigned int off = 1; off < 1024; off <<= 1) {      // inclusive scan
+    unsigned int v = (t >= off) ? s_cnt[t - off] : 0u;
+    __syncthreads();
+    s_cnt[t] += v;
+    __syncthreads();
+  }
+  const unsigned int total = s_cnt[1023];
+  unsigned int hpos = s_cnt[t] - c;                         // heavy waves before this chunk
+  unsigned int lpos = total + (lo - hpos);                  // light waves go after all heavy ones
+  for (unsigned int i = lo; i < hi; i++) { if (flags[i]) order[hpos++] = i; else order[lpos++] = i; }
+}
+
 // level 0: camera / lens ray generation (Camera.h:65-67, 189-190) + closest hit, one 8x8 pixel tile per wave
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, RenderArgs A, PathNode *nodes, Stats *gstats)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_primary(DevScene sc, RenderArgs A, PathNode *nodes, const unsigned int *order,
+                                                                    unsigned char *shadow_flags, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
-  const unsigned int wave = xcd_remap(blockIdx.x, gridDim.x) * RT_WAVES + (threadIdx.x >> 6);
+  const unsigned int slot = xcd_remap(blockIdx.x, gridDim.x) * RT_WAVES + (threadIdx.x >> 6);
+  const unsigned int wave = order ? (unsigned int)uni((int)order[slot]) : slot;
   const unsigned int lane = threadIdx.x & 63;
   // 8x8-pixel tile per wave; tiles are numbered super-tile by super-tile (16x8 tiles = 128x64 pixels =
   // 128 waves = one XCD chunk of blocks), so that an XCD's L2 sees a compact 2-D patch of the image
-  const unsigned int sx = (A.tiles_x + 15) / 16, sy = (A.tiles_y + 7) / 8;
-  const unsigned int per_sample = sx * sy * 128;
-  const unsigned int s_local = wave / per_sample, wi = wave % per_sample;
-  const unsigned int st_i = wi / 128, in_st = wi % 128;
-  const unsigned int tx = (st_i % sx) * 16 + (in_st % 16), ty = (st_i / sx) * 8 + (in_st / 16);
+  unsigned int s_local, tx, ty; tile_of_wave(A, wave, s_local, tx, ty);
   const unsigned int h = tx * 8 + (lane & 7);
   const unsigned int v = A.v_lo + ty * 8 + (lane >> 3);
   const uint64_t p = (uint64_t)v * A.cam.W + h;
@@ -405,7 +483,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, RenderArgs A,
   V3 d = unitize(unitize(cur - o));     // Camera.h:67 + CRay ctor (Geometry.h:253-254)
   RayState r; ray_setup(r, o, d, sc.coord_scale);
   if (STATS && active) st.rays++;
-  traverse<false, STATS>(sc, r, active, false, mk(0, 0, 0), stack, st);
+  trace_closest<STATS>(sc, r, active, stack, st);
   if (active) {
     PathNode &nd = nodes[(uint64_t)wave * 64 + lane];     // level 0 is stored in tile order (see node_of_pixel)
     nd.o[0] = o.x; nd.o[1] = o.y; nd.o[2] = o.z; nd.d[0] = d.x; nd.d[1] = d.y; nd.d[2] = d.z;
@@ -413,7 +491,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_primary(DevScene sc, RenderArgs A,
     nd.pixel = (uint32_t)p; nd.sample = sample; nd.path = 1;
     nd.child_refr = -1; nd.child_refl = -1; nd.w_refr = 0; nd.w_refl = 0;
   }
-  else {
+  if (shadow_flags) {
+    // will this wave's shadow pass meet the tree?  (first light only: it orders work, nothing else)
+    bool heavy = false;
+    if (active && r.best_id >= 0 && sc.n_lights > 0) {
+      const DLight &L0 = sc.lights[0];
+      const V3 pt = o + d * r.best_t, lp = mk(L0.p[0], L0.p[1], L0.p[2]);
+      heavy = ray_meets_box(pt, unitize(L0.type == 101 ? neg(lp) : lp - pt), sc.rbmin, sc.rbmax);
+    }
+    const unsigned long long hm = __ballot(heavy);
+    if (lane == 0) shadow_flags[wave] = hm ? 1 : 0;
+  }
+  if (!active) {
     PathNode &nd = nodes[(uint64_t)wave * 64 + lane];     // padding lane of an edge tile: a miss nobody reads
     nd.id = -1; nd.t = kMiss; nd.weight = 0; nd.pixel = 0; nd.sample = 0; nd.path = 1;
     nd.child_refr = -1; nd.child_refl = -1; nd.w_refr = 0; nd.w_refl = 0;
@@ -435,7 +524,7 @@ __device__ __forceinline__ uint64_t node_of_pixel(const RenderArgs &A, uint64_t 
 
 // levels >= 1: closest hit for queued secondary rays
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n, Stats *gstats)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
@@ -446,7 +535,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_nodes(DevScene sc, PathNode 
   if (active) { o = mk(nodes[i].o[0], nodes[i].o[1], nodes[i].o[2]); d = mk(nodes[i].d[0], nodes[i].d[1], nodes[i].d[2]); }
   RayState r; ray_setup(r, o, d, sc.coord_scale);
   if (STATS && active) st.rays++;
-  traverse<false, STATS>(sc, r, active, false, mk(0, 0, 0), stack, st);
+  trace_closest<STATS>(sc, r, active, stack, st);
   if (active) { nodes[i].t = r.best_t; nodes[i].id = r.best_id; }
   if (STATS) stats_flush(gstats, st);
 }
@@ -454,14 +543,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_nodes(DevScene sc, PathNode 
 // Shadow pass: luminosity of every light at every hit node (Scene.h:104-109), one wave-packet
 // occlusion walk per light sample.  Kept apart from k_shade so that the walk runs at full occupancy.
 template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n, double *lum,
-                                                      RenderCounters *cnt, Stats *gstats)
+__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n, double *lum,
+                                                      const unsigned int *order, RenderCounters *cnt, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
-  const unsigned int i = xcd_remap(blockIdx.x, gridDim.x) * RT_BLOCK + threadIdx.x;
+  const unsigned int slot = xcd_remap(blockIdx.x, gridDim.x) * RT_WAVES + (threadIdx.x >> 6);
+  const unsigned int i = (order ? (unsigned int)uni((int)order[slot]) : slot) * 64 + (threadIdx.x & 63);
   const bool in_range = i < n;
   Stats st{};
+#ifdef RT_STAMPS
+  stamp(i >> 6, 0);
+#endif
   int id = -1; double t = kMiss; V3 o = mk(0, 0, 0), d = mk(1, 0, 0);
   RngKey key; key.seed = A.seed; key.pixel = 0; key.sample = 0; key.path = 1;
   if (in_range) {
@@ -480,6 +573,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shadow(DevScene sc, RenderArgs A, 
   // ray census (always on: it is what rt_hip_last_ray_count reports)
   for (int off = 32; off > 0; off >>= 1) my_shadow += __shfl_down(my_shadow, off, 64);
   if ((threadIdx.x & 63) == 0 && my_shadow) atomicAdd(&cnt->shadow_rays, my_shadow);
+#ifdef RT_STAMPS
+  stamp(i >> 6, 1);
+#endif
   if (STATS) stats_flush(gstats, st);
 }
 
@@ -644,7 +740,7 @@ extern "C" int rt_hip_get_stats(rt_hip_ctx *ctx, rt_hip_stats *out, int reset)
   Stats s;
   HIP_TRY(hipMemcpy(&s, ctx->d_stats, sizeof s, hipMemcpyDeviceToHost));
   out->rays = s.rays; out->shadow_rays = s.shadow_rays; out->node_visits = s.node_visits; out->prim_tests = s.prim_tests;
-  out->exact_tests = s.exact_tests; out->wave_node_visits = s.wave_nodes; out->wave_prim_tests = s.wave_prims; out->reserved = 0;
+  out->exact_tests = s.exact_tests; out->wave_node_visits = s.wave_nodes; out->wave_prim_tests = s.wave_prims; out->reserved = s.pad;
   if (reset) HIP_TRY(hipMemset(ctx->d_stats, 0, sizeof(Stats)));
   return RT_HIP_OK;
 }
@@ -656,7 +752,7 @@ extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
   for (void *p : s->allocs) (void)hipFree(p);
   for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &b : s->levels) b.release();
-  s->counter.release(); s->staging.release(); s->lum.release();
+  s->counter.release(); s->staging.release(); s->lum.release(); s->order.release();
   delete s;
   return RT_HIP_OK;
 }
@@ -698,7 +794,8 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   HIP_TRY(hipSetDevice(ctx->device));
   rt_hip_scene *s = new rt_hip_scene();
   s->ctx = ctx;
-  Builder B; B.d = d; B.leaf_refine = leaf_refine;
+  Builder B; B.d = d;
+  B.leaf_refine = (leaf_refine == RT_HIP_LEAF_REFINE_DEFAULT) ? 32u : (leaf_refine == RT_HIP_LEAF_REFINE_NONE ? 0u : leaf_refine);
   // triangles: m_norm = ((v1 - v0) ^ (v2 - v0)).Unitize(), Object.h:365
   B.tri_exact.resize(d->n_triangles);
   std::vector<TriShade> tri_shade(d->n_triangles);
@@ -728,6 +825,7 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
       root_ref = ChildRef{-1, (int32_t)(off / 64)};
     } else {
       root_ref = root.ref;
+      for (int a = 0; a < 3; a++) { s->dev.rbmin[a] = root.box.mn[a]; s->dev.rbmax[a] = root.box.mx[a]; }
       for (int a = 0; a < 3; a++) cs = std::max(cs, std::max(std::fabs(root.box.mn[a]), std::fabs(root.box.mx[a])));
     }
     if (B.pairs.empty()) B.pairs.emplace_back();
@@ -915,11 +1013,25 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   Stats *gs = stats ? s->ctx->d_stats : nullptr;
   const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
   PathNode *L0 = (PathNode *)s->levels[0].p;
+  // heavy-first order of the level-0 waves (only worth it with a tree)
+  unsigned int *order0 = nullptr, *order1 = nullptr; unsigned char *flags0 = nullptr, *flags1 = nullptr;
+  if (s->dev.has_tree) {
+    rc = s->order.ensure(n_waves * 10 + 64); if (rc) return rc;
+    order0 = (unsigned int *)s->order.p; order1 = order0 + n_waves;
+    flags0 = (unsigned char *)(order1 + n_waves); flags1 = flags0 + n_waves;
+    ProfScope ps(s, RT_HIP_K_PRIMARY, st);
+    hipLaunchKernelGGL(k_classify, dim3((unsigned int)((n_waves + 255) / 256)), dim3(256), 0, st, s->dev, A, (unsigned int)n_waves, flags0);
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, order0);
+  }
   {
     ProfScope ps(s, RT_HIP_K_PRIMARY, st);
-    if (stats) hipLaunchKernelGGL(k_primary<true>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, gs);
-    else hipLaunchKernelGGL(k_primary<false>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, gs);
+    if (stats) hipLaunchKernelGGL(k_primary<true>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, (const unsigned int *)order0, flags1, gs);
+    else hipLaunchKernelGGL(k_primary<false>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, (const unsigned int *)order0, flags1, gs);
   }
+  if (s->dev.has_tree && s->dev.n_lights > 0) {
+    ProfScope ps(s, RT_HIP_K_SHADOW, st);
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags1, (unsigned int)n_waves, order1);
+  } else order1 = nullptr;
   HIP_TRY(hipGetLastError());
   unsigned int n_level[rt_hip_scene::kMaxLevels] = {0};
   n_level[0] = (unsigned int)n0;
@@ -949,8 +1061,9 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     double *lum = (double *)s->lum.p;
     if (s->dev.n_lights > 0) {
       ProfScope ps(s, RT_HIP_K_SHADOW, st);
-      if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, (const PathNode *)cur, n, lum, cnt, gs);
-      else hipLaunchKernelGGL(k_shadow<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, (const PathNode *)cur, n, lum, cnt, gs);
+      const unsigned int *ord = (lv == 0) ? (const unsigned int *)order1 : nullptr;
+      if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, (const PathNode *)cur, n, lum, ord, cnt, gs);
+      else hipLaunchKernelGGL(k_shadow<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, (const PathNode *)cur, n, lum, ord, cnt, gs);
     }
     {
       ProfScope ps(s, RT_HIP_K_SHADE, st);

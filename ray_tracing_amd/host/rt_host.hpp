@@ -196,6 +196,7 @@ class Scene {                    // CScene, Scene.h:12-60
   const std::vector<rt_hip_triangle> &Triangles() const { return triangles_; }
 
   // ---- device ----
+  // RT_HIP_LEAF_REFINE_DEFAULT / RT_HIP_LEAF_REFINE_NONE / a leaf size (acceleration only, results unchanged)
   void SetLeafRefine(uint32_t n) { leaf_refine_ = n; dirty_ = true; }
   rt_hip_scene *Device(Context &ctx)
   {
@@ -322,7 +323,7 @@ class Scene {                    // CScene, Scene.h:12-60
   std::vector<Box> boxes_;
   std::vector<rt_hip_node> nodes_; std::vector<uint32_t> refs_, root_objects_;
   int max_obj_ = 100, max_depth_ = 40;
-  uint32_t leaf_refine_ = 0;
+  uint32_t leaf_refine_ = RT_HIP_LEAF_REFINE_DEFAULT;
   rt_hip_scene *dev_ = nullptr; rt_hip_ctx *dev_ctx_ = nullptr; bool dirty_ = true;
 };
 

@@ -42,7 +42,7 @@ class _Pair:
         return out
 
 
-def build_icosahedron(material="plastic", light="point_area", gpu=True, oracle=True, bsp=True, leaf_refine=0,
+def build_icosahedron(material="plastic", light="point_area", gpu=True, oracle=True, bsp=True, leaf_refine=None,
                       extra_sphere=False):
     """C1: Layout3_Icosahedron (Layout.h:136-160) without textures.
     light: 'point_area' = AddAreaLight((-10,20,20),1,0,1) (deterministic), 'area10' = Layout.h:155,
@@ -71,7 +71,7 @@ def build_icosahedron(material="plastic", light="point_area", gpu=True, oracle=T
     elif light == "two":
         P.call("add_area_light", (-10, 20, 20), 0.6, 4.0, 2)
         P.call("add_parallel_light", (1, 1, -1), 0.5)
-    if P.g is not None and leaf_refine:
+    if P.g is not None and leaf_refine is not None:
         P.g.set_leaf_refine(leaf_refine)
     return P.g, P.o
 
@@ -101,7 +101,7 @@ def heightfield_triangles(n_cells=708, half=5.0):
 C2_CAMERA = dict(view=(-12, -9, 7), eye=(12, 9, -7), left=(9, -12, 0), dist=20, hor=19.2, ver=10.8, res=100, depth=1)
 
 
-def build_heightfield(n_cells=708, gpu=True, oracle=True, leaf_refine=0, max_obj_num=0):
+def build_heightfield(n_cells=708, gpu=True, oracle=True, leaf_refine=None, max_obj_num=0):
     """C2: ground plane z=-1 (id 0) + heightfield, plastic, point-like area light."""
     P = _Pair(0.5, gpu, oracle)
     plastic = P.mat("plastic")
@@ -110,7 +110,7 @@ def build_heightfield(n_cells=708, gpu=True, oracle=True, leaf_refine=0, max_obj
     P.call("add_triangles", tris, mat=plastic, colour=(90, 160, 60))
     P.call("construct_bsp", max_obj_num, 0)
     P.call("add_area_light", (-10, 20, 20), 1.0, 0.0, 1)
-    if P.g is not None and leaf_refine:
+    if P.g is not None and leaf_refine is not None:
         P.g.set_leaf_refine(leaf_refine)
     return P.g, P.o
 

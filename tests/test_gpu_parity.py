@@ -44,7 +44,7 @@ def test_c1_hit_ids_bsp_and_brute(ctx):
     _compare_hits(rays[sub], hb, ids_ref[sub], pts_ref[sub], "C1 brute")
 
 
-@pytest.mark.parametrize("refine", [0, 8])
+@pytest.mark.parametrize("refine", [0xFFFFFFFF, 0, 8])
 def test_random_rays_mixed_scene(ctx, refine):
     g, o = scenes.build_icosahedron(extra_sphere=True, leaf_refine=refine)
     rng = np.random.default_rng(7)
@@ -182,3 +182,35 @@ def test_pixel_shards_reassemble(ctx):
         check(rta.hip.rt_hip_render_whitted(g.device(ctx), cam.raw, q, out.ctypes.data, None))
         parts.append(out)
     assert (np.concatenate(parts) == full).all()
+
+
+def test_c2_full_size_heightfield(ctx):
+    """BASELINE configs[1] at full size (1,002,528 triangles, 1920x1080): hit ids on the 8-pixel grid
+    (32,400 rays) and radiance (primary + shadow) on three full image rows against the oracle."""
+    import ray_tracing_amd as rta
+    g, o = scenes.build_heightfield(708)
+    gs, _ = g.tree_stats()
+    os_, _ = o.tree_stats()
+    assert gs == os_                      # 1M-triangle BSP build: host flatten == oracle pointer tree
+    print("C2 tree: nodes %d leaves %d empty %d refs %d depth %d max leaf %d" % tuple(gs[:6]))
+    cam = rta.Camera(**scenes.C2_CAMERA)
+    cam.render_raytracer(ctx, g, background=(200, 200, 200))
+    rgb, ids = cam.rgb().reshape(cam.height, cam.width, 3), cam.prim_id().reshape(cam.height, cam.width)
+    rays, w, h = o.camera_rays(scenes.oracle_camera(scenes.C2_CAMERA))
+    rays = rays.reshape(h, w, 6)
+    grid = rays[4::8, 4::8].reshape(-1, 6)
+    ids_ref, pts_ref = o.trace_closest(grid, use_bsp=True)
+    got = ids[4::8, 4::8].reshape(-1)
+    mism = np.nonzero(got != ids_ref)[0]
+    print("C2 grid: %d rays, %d id mismatches" % (len(got), len(mism)))
+    if len(mism):
+        hits = g.first_inter_pt(ctx, grid[mism])
+        t_ref = np.linalg.norm(pts_ref[mism] - grid[mism, :3], axis=1)
+        assert np.abs(hits["t"] - t_ref).max() < 1e-6
+    assert len(mism) / len(got) <= 1e-4
+    ocam = scenes.oracle_camera(scenes.C2_CAMERA)
+    for row in (300, 540, 800):
+        ref_rgb, ref_ids = o.render_whitted(ocam, background=(200, 200, 200), first=row * w, count=w)
+        same = ids[row] == ref_ids
+        assert same.mean() >= 1 - 1e-3
+        assert _rel_err(rgb[row][same], ref_rgb[same]).max() < 1e-3

@@ -26,3 +26,11 @@ def test_c1_hit_id_hash_matches_survey():
     # BSP vs brute force: 0 mismatches
     ids2, _ = o.trace_closest(rays, use_bsp=False)
     assert (ids == ids2).all()
+
+
+def test_c2_tree_statistics_match_survey():
+    """the reference's own BSP build of the 1,002,528-triangle heightfield gave 67,281 nodes,
+    33,641 leaves (4,450 empty), 1,832,852 leaf references, max depth 20, max leaf 99."""
+    _, o = scenes.build_heightfield(708, gpu=False)
+    st, _ = o.tree_stats()
+    assert st[:6] == [67281, 33641, 4450, 1832852, 20, 99]
