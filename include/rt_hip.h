@@ -209,7 +209,8 @@ int rt_hip_render_focusing_dev(rt_hip_scene *scene, const rt_hip_camera *cam, co
 #define RT_HIP_K_TRACE_CLOSEST  5   /* rt_hip_trace_closest(_dev) */
 #define RT_HIP_K_TRACE_OCCLUDED 6
 #define RT_HIP_K_SHADOW         7   /* luminosity of every light at every hit: occlusion walks */
-#define RT_HIP_K_COUNT          8
+#define RT_HIP_K_ORDER          8   /* heavy-first work ordering (classification + stable partition) */
+#define RT_HIP_K_COUNT          12
 typedef struct { double ms[RT_HIP_K_COUNT]; uint64_t launches[RT_HIP_K_COUNT]; } rt_hip_profile;
 int rt_hip_set_profiling(rt_hip_scene *scene, int on);
 /* synchronises the device, adds up the recorded events; reset = 1 clears the sums */

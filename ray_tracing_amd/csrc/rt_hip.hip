@@ -1019,7 +1019,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     rc = s->order.ensure(n_waves * 10 + 64); if (rc) return rc;
     order0 = (unsigned int *)s->order.p; order1 = order0 + n_waves;
     flags0 = (unsigned char *)(order1 + n_waves); flags1 = flags0 + n_waves;
-    ProfScope ps(s, RT_HIP_K_PRIMARY, st);
+    ProfScope ps(s, RT_HIP_K_ORDER, st);
     hipLaunchKernelGGL(k_classify, dim3((unsigned int)((n_waves + 255) / 256)), dim3(256), 0, st, s->dev, A, (unsigned int)n_waves, flags0);
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, order0);
   }
@@ -1029,7 +1029,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     else hipLaunchKernelGGL(k_primary<false>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, (const unsigned int *)order0, flags1, gs);
   }
   if (s->dev.has_tree && s->dev.n_lights > 0) {
-    ProfScope ps(s, RT_HIP_K_SHADOW, st);
+    ProfScope ps(s, RT_HIP_K_ORDER, st);
     hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags1, (unsigned int)n_waves, order1);
   } else order1 = nullptr;
   HIP_TRY(hipGetLastError());

@@ -101,7 +101,7 @@ def heightfield_triangles(n_cells=708, half=5.0):
 C2_CAMERA = dict(view=(-12, -9, 7), eye=(12, 9, -7), left=(9, -12, 0), dist=20, hor=19.2, ver=10.8, res=100, depth=1)
 
 
-def build_heightfield(n_cells=708, gpu=True, oracle=True, leaf_refine=None, max_obj_num=0):
+def build_heightfield(n_cells=708, gpu=True, oracle=True, leaf_refine=None, max_obj_num=0, light=True):
     """C2: ground plane z=-1 (id 0) + heightfield, plastic, point-like area light."""
     P = _Pair(0.5, gpu, oracle)
     plastic = P.mat("plastic")
@@ -109,7 +109,8 @@ def build_heightfield(n_cells=708, gpu=True, oracle=True, leaf_refine=None, max_
     tris = heightfield_triangles(n_cells)
     P.call("add_triangles", tris, mat=plastic, colour=(90, 160, 60))
     P.call("construct_bsp", max_obj_num, 0)
-    P.call("add_area_light", (-10, 20, 20), 1.0, 0.0, 1)
+    if light:
+        P.call("add_area_light", (-10, 20, 20), 1.0, 0.0, 1)
     if P.g is not None and leaf_refine is not None:
         P.g.set_leaf_refine(leaf_refine)
     return P.g, P.o
