@@ -134,6 +134,20 @@ __device__ __forceinline__ bool occludes(V3 o, V3 d, double t, bool has_ref, V3 
   return dot(o - X, ref - X) < -kEps;
 }
 
+// Diagnostic build only (-DRT_TIMERS): shader-clock cycles per section of the walk, summed over waves.
+#ifdef RT_TIMERS
+__device__ unsigned long long g_timers[16];
+#define RT_TM_DECL unsigned long long tm_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_readcyclecounter();
+#define RT_TM(k) { unsigned long long tm_n = __builtin_readcyclecounter(); tm_[k] += tm_n - tm_t; tm_t = tm_n; }
+#define RT_TM_CNT(k) { tm_[k]++; }
+#define RT_TM_FLUSH { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_timers[k_ + (ANY ? 8 : 0)], tm_[k_]); }
+#else
+#define RT_TM_DECL
+#define RT_TM(k)
+#define RT_TM_CNT(k)
+#define RT_TM_FLUSH
+#endif
+
 struct RayState {
   V3 o, d;
   V3 inv;             // 1/d per axis, +-1e30 for a (near) zero component so that the slab products stay finite
@@ -144,6 +158,7 @@ struct RayState {
   double mscale;      // per-ray scale of the barycentric margin
   double gmin;        // per-ray |d.n| threshold below which the cull is not trusted
   double tlow;        // scale of the margin of the t > eps test: tlow / |d.n|
+  unsigned dsign;     // bit a set: d[a] >= 0 (near-child order of the packet, never results)
 };
 
 __device__ __forceinline__ double safe_inv(double x) { return (fabs(x) < 1e-30) ? ((x < 0) ? -1e30 : 1e30) : 1.0 / x; }
@@ -166,6 +181,20 @@ __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_
   // near t = 0 (rays that start on a surface) the error of t' is the rounding of dpl - o.n (a few ulp of s)
   // over |d.n|: 16 ulp(s) / |d.n| bounds it, and keeps a ray's own triangle (t' ~ 1e-15) out of the survivors
   r.tlow = 16.0 * 2.3e-16 * s;
+  r.dsign = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
+}
+
+// A DPair through the scalar data path: the index is wave-uniform, so the 128 bytes arrive as two
+// s_load_dwordx16 in SGPRs with ONE wait, and the slab tests take the box as scalar operands.
+// (Left to the compiler, the pair came in through five dependent vector-memory round trips.)
+typedef const __attribute__((address_space(4))) DPair *PairScalarPtr;
+__device__ __forceinline__ DPair load_pair(const DPair *pairs, int i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(PairScalarPtr)(unsigned long long)(pairs + i);
+#else
+  return pairs[i];   // host pass of the compiler only parses this
+#endif
 }
 
 // branch-free slab test against an (inflated) box: does the ray overlap it for some t in (0, bound]?
@@ -243,27 +272,34 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
     }
   };
   int sp = 0;
-  lds->stack[0] = sc.root; sp = 1;
-  while (sp > 0) {
-    --sp;
-    const int i0 = uni(lds->stack[sp].i0), i1 = uni(lds->stack[sp].i1);
+  ChildRef cur = sc.root;
+  bool have = true;                                // `cur` holds the next node (the near child); else pop
+  RT_TM_DECL
+  while (true) {
+    if (!have) {
+      if (sp == 0) break;
+      --sp;
+      cur.i0 = uni(lds->stack[sp].i0); cur.i1 = uni(lds->stack[sp].i1);
+    }
+    have = false;
+    const int i0 = cur.i0, i1 = cur.i1;
     const bool live = active && !(ANY && found);
     if (__ballot(live) == 0ull) break;            // every ray of the wave is finished
+    RT_TM(0)
     if (i0 >= 0) {
       // ---- inner node: fetch both child boxes at once, keep the children some lane wants ----
-      const DPair &P = sc.pairs[i0];
-      const bool wl = live && slab(r, P.lmin, P.lmax);
-      const bool wr = live && slab(r, P.rmin, P.rmax);
+      const DPair P = load_pair(sc.pairs, i0);
+      const bool wl = slab(r, P.lmin, P.lmax) & live;
+      const bool wr = slab(r, P.rmin, P.rmax) & live;
       if (STATS) { if (live) st.node_visits += 2; if ((threadIdx.x & 63) == 0) st.wave_nodes += 2; }
       const unsigned long long ml = __ballot(wl), mr = __ballot(wr);
-      const int axis = uni(P.axis);
-      const double da = (axis == 0) ? r.d.x : ((axis == 1) ? r.d.y : r.d.z);
-      const unsigned long long pos = __ballot((wl || wr) && (da >= 0.0));
+      const unsigned long long pos = __ballot((wl | wr) & (((r.dsign >> P.axis) & 1u) != 0u));
       const bool left_first = (2 * __popcll(pos) >= __popcll(ml | mr));
-      const ChildRef L = P.l, R = P.r;
-      // push far first so that the near child is popped next
-      if (left_first) { if (mr) lds->stack[sp++] = R; if (ml) lds->stack[sp++] = L; }
-      else            { if (ml) lds->stack[sp++] = L; if (mr) lds->stack[sp++] = R; }
+      // continue with the near child; the far one waits on the stack
+      if (ml != 0ull && mr != 0ull) { lds->stack[sp++] = left_first ? P.r : P.l; cur = left_first ? P.l : P.r; have = true; }
+      else if (ml != 0ull) { cur = P.l; have = true; }
+      else if (mr != 0ull) { cur = P.r; have = true; }
+      RT_TM(1) RT_TM_CNT(5)
     } else {
       // ---- leaf: stage header + records in LDS chunk by chunk ----
       const int cnt = -1 - i0;
@@ -272,12 +308,14 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
       for (int c0 = 0; c0 < cnt; c0 += RT_CHUNK_RECS) {
         const int nrec = (cnt - c0 < RT_CHUNK_RECS) ? (cnt - c0) : RT_CHUNK_RECS;
         stage_chunk(base + (size_t)c0 * sizeof(LeafRec), lds->leaf, 64 + nrec * (int)sizeof(LeafRec));
+        RT_TM(2) RT_TM_CNT(6)
         if (c0 == 0) {
           const LeafHeader *H = (const LeafHeader *)lds->leaf;
           want = live && slab(r, H->bmin, H->bmax);
           if (STATS) { if (live) st.node_visits++; if ((threadIdx.x & 63) == 0) st.wave_nodes++; }
           if (__ballot(want) == 0ull) break;
         }
+        RT_TM(3)
         const LeafRec *recs = (const LeafRec *)(lds->leaf + 64);
 #ifdef RT_UNROLL
 #pragma unroll RT_UNROLL
@@ -335,9 +373,14 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
         }
         // the next chunk overwrites the LDS image: all reads above are complete (values consumed)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RT_TM(4)
+#ifdef RT_TIMERS
+        tm_[7] += nrec;
+#endif
       }
     }
   }
+  RT_TM_FLUSH
 }
 
 // Closest hit of one ray per lane (CScene::FirstInterPt_BSPTree, Scene.h:85-91; FirstInterPt, Scene.h:62-83,

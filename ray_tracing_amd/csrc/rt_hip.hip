@@ -284,7 +284,7 @@ int upload(rt_hip_scene *s, const std::vector<T> &v, const T **out)
 #define RT_BLOCK 64     /* one wave per workgroup: waves of very different cost pack the CUs best (measured) */
 #endif
 #ifndef RT_MINWAVES
-#define RT_MINWAVES 1   /* __launch_bounds__ second argument: minimum waves per SIMD */
+#define RT_MINWAVES 4   /* __launch_bounds__ second argument: 4 waves per SIMD = a 128-VGPR budget (no spills at 125) */
 #endif
 #define RT_WAVES (RT_BLOCK / 64)
 
@@ -295,6 +295,15 @@ __device__ __forceinline__ void stamp(unsigned int wave, int which)
 {
   if ((threadIdx.x & 63) == 0 && wave < RT_MAX_STAMPS) g_stamps[2 * wave + which] = wall_clock64();
 }
+#ifdef RT_TIMERS
+extern "C" int rt_hip_debug_read_timers(unsigned long long *out, int reset)
+{
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_timers), 16 * 8, 0, hipMemcpyDeviceToHost));
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_timers), z, sizeof z, 0, hipMemcpyHostToDevice)); }
+  return 0;
+}
+#endif
 extern "C" int rt_hip_debug_read_stamps(unsigned long long *out, size_t n_waves)
 {
   if (n_waves > RT_MAX_STAMPS) n_waves = RT_MAX_STAMPS;
