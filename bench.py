@@ -3,8 +3,11 @@
 synthetic 1,002,528-triangle heightfield + ground plane, primary + shadow ray casting at 1920x1080
 (SURVEY 8d C2), through the rt_hip_* C ABI with every input resident in HBM.
 
-A "step" = one full frame: camera-ray generation + closest hit (k_primary), then shading with one
-shadow query per hit pixel (k_shade), then the resolve to an RGB f64 frame.
+A "step" = one full frame: camera-ray generation + closest hit (k_primary), one shadow query per hit
+pixel (k_shadow), shading (k_shade) and the resolve to an RGB f64 frame.  `--streams S` (default 2) keeps S
+frames in flight per GPU, frame k on stream k % S with its own rt_hip_scene_share handle: wave costs in
+these kernels differ 50x, and the draining tail of one frame is filled by the next frame's waves.  The time
+per frame with one frame in flight is reported beside it (config.ms_per_frame_one_in_flight).
 
 Multi-GPU (one process per GPU, torchrun): C2 is a deterministic ray cast, so ranks render
 independent frames (rank r renders the camera of frame step*N + r on a small orbit): the path
@@ -38,6 +41,7 @@ def main():
     ap.add_argument("--cells", type=int, default=708, help="heightfield cells per side (708 -> 1,002,528 triangles)")
     ap.add_argument("--leaf-refine", type=int, default=None, help="library leaf refinement (default: library default, 32)")
     ap.add_argument("--mode", choices=["frames", "samples"], default="frames")
+    ap.add_argument("--streams", type=int, default=2, help="frames in flight per GPU (one scene handle and HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
     args = ap.parse_args()
@@ -87,6 +91,14 @@ def main():
     params = rta.Params(background=(200, 200, 200))
     stream = torch.cuda.current_stream()
     sptr = C.c_void_p(stream.cuda_stream)
+    # frames in flight: frame k runs on stream k % S with its own scene handle (the handle owns the per-frame
+    # scratch), so the low-occupancy tail of one frame's kernels is filled by the next frame's waves
+    S = max(1, args.streams)
+    fl_streams = [stream] + [torch.cuda.Stream() for _ in range(S - 1)]
+    fl_scenes_keep = [gscene.share(ctx) for _ in range(S - 1)]
+    fl_scenes = [raw_scene] + [sh.raw for sh in fl_scenes_keep]
+    fl_rgb = [[torch.zeros(npix * 3, dtype=torch.float64, device=dev) for _ in range(2)] for _ in range(S)]
+    fl_prim = [prim] + [torch.zeros(npix, dtype=torch.int32, device=dev) for _ in range(S - 1)]
     comm_stream = torch.cuda.Stream() if (world > 1 and args.mode == "samples") else None
 
     def render(step, buf):
@@ -94,16 +106,17 @@ def main():
         cam = cam0 if frame == 0 else camera_for(frame)
         if args.mode == "samples":
             params.seed = step * world + rank
-        rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cam.raw, params, C.c_void_p(buf.data_ptr()),
-                                                    C.c_void_p(prim.data_ptr()), sptr))
+        k = step % S
+        rta.check(rta.hip.rt_hip_render_whitted_dev(fl_scenes[k], cam.raw, params, C.c_void_p(buf.data_ptr()),
+                                                    C.c_void_p(fl_prim[k].data_ptr()), C.c_void_p(fl_streams[k].cuda_stream)))
         return cam
 
     def one_step(step):
-        buf = rgb[step & 1]
+        buf = fl_rgb[step % S][(step // S) & 1]
         cam = render(step, buf)
         if comm_stream is not None:
             # radiance all-reduce of this step overlaps the next step's render
-            comm_stream.wait_stream(stream)
+            comm_stream.wait_stream(fl_streams[step % S])
             with torch.cuda.stream(comm_stream):
                 dist.all_reduce(buf)
         return cam
@@ -151,6 +164,15 @@ def main():
     ev_ms = ev0.elapsed_time(ev1)
     rta.check(rta.hip.rt_hip_get_profile(raw_scene, C.byref(prof), 1))
     rta.check(rta.hip.rt_hip_set_profiling(raw_scene, 0))
+
+    # for reference, outside the timed region: the same frames strictly one after the other
+    t1 = time.perf_counter()
+    n_one = min(args.steps, 10)
+    for s_ in range(n_one):
+        rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, camera_for(s_ * world + rank).raw if args.mode == "frames" else cam0.raw, params,
+                                                    C.c_void_p(fl_rgb[0][0].data_ptr()), C.c_void_p(prim.data_ptr()), sptr))
+    torch.cuda.synchronize()
+    ms_one_in_flight = (time.perf_counter() - t1) * 1e3 / n_one
 
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -238,7 +260,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "C2: synthetic %d-triangle heightfield + ground plane, primary+shadow ray casting %dx%d, 1 frame per GPU per step"
                                   % (n_tris, W, H), "triangles": n_tris, "resolution": [W, H], "rays_per_frame": int(rays_per_frame),
-                      "shadow_rays_per_frame": int(shadow_pf.value), "parallelism": "%s x%d" % (args.mode, world),
+                      "shadow_rays_per_frame": int(shadow_pf.value), "parallelism": "%s x%d" % (args.mode, world), "frames_in_flight": S, "ms_per_frame_one_in_flight": round(ms_one_in_flight, 4),
                       "leaf_refine": "library default (32)" if args.leaf_refine is None else args.leaf_refine, "scene_build_s": round(build_s, 2), "event_ms_per_step": round(ev_ms / args.steps, 4)},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)

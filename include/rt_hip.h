@@ -162,6 +162,11 @@ int rt_hip_get_stats(rt_hip_ctx *ctx, rt_hip_stats *out, int reset);
 #define RT_HIP_LEAF_REFINE_NONE    0xFFFFFFFFu
 int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *desc, uint32_t leaf_refine, rt_hip_scene **out);
 int rt_hip_scene_destroy(rt_hip_scene *scene);
+/* Another handle on the same scene: shares the geometry in HBM (released with the last handle), owns its
+ * render workspace.  One handle serves one call at a time; two handles may render concurrently on two
+ * streams.  The reference passes CScene BY VALUE into every RayTracer call (RayTracer.h:8) - a copy per ray;
+ * this is the one copy per frame in flight that remains of it. */
+int rt_hip_scene_share(rt_hip_scene *scene, rt_hip_scene **out);
 
 /* ---- queries --------------------------------------------------------------------- */
 /* CScene::FirstInterPt_BSPTree(ray, record) (Scene.h:85-91) for n rays.

@@ -125,6 +125,8 @@ hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Pa
 hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_render_focusing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp]
 hip.rt_hip_render_focusing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
+hip.rt_hip_scene_share.argtypes = [_vp, C.POINTER(_vp)]
+hip.rt_hip_scene_destroy.argtypes = [_vp]
 hip.rt_hip_set_profiling.argtypes = [_vp, C.c_int]
 hip.rt_hip_get_profile.argtypes = [_vp, C.POINTER(Profile), C.c_int]
 hip.rt_hip_last_ray_count.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -184,6 +186,20 @@ class Context:
         if getattr(self, "_h", None):
             host.rth_context_free(self._h)
             self._h = None
+
+
+class SharedScene:
+    """rt_hip_scene_share handle; keeps its parent alive"""
+
+    def __init__(self, parent, ctx):
+        self._parent, self._ctx = parent, ctx
+        self.raw = _vp()
+        check(hip.rt_hip_scene_share(parent.device(ctx), C.byref(self.raw)))
+
+    def __del__(self):
+        if getattr(self, "raw", None):
+            hip.rt_hip_scene_destroy(self.raw)
+            self.raw = None
 
 
 class Scene:
@@ -265,6 +281,10 @@ class Scene:
         raw = _vp()
         _chk_host(host.rth_scene_device(self._h, ctx._h, C.byref(raw)))
         return raw
+
+    def share(self, ctx):
+        """another rt_hip_scene* on the same geometry with its own render workspace (a frame in flight)"""
+        return SharedScene(self, ctx)
 
     def first_inter_pt(self, ctx, rays, use_tree=True, record=True):
         """CScene::FirstInterPt_BSPTree / FirstInterPt for an (n,6) array of rays"""

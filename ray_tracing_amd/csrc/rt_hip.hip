@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 using namespace rt;
@@ -68,7 +69,9 @@ static_assert(sizeof(PathNode) == 128, "PathNode layout");
 struct rt_hip_scene {
   rt_hip_ctx *ctx = nullptr;
   DevScene dev{};
-  std::vector<void *> allocs;     // scene arrays
+  // scene arrays in HBM; shared (read-only) by the handles made with rt_hip_scene_share
+  struct Geometry { std::vector<void *> allocs; ~Geometry() { for (void *p : allocs) (void)hipFree(p); } };
+  std::shared_ptr<Geometry> geo = std::make_shared<Geometry>();
   // render workspace (grow-only, reused between calls)
   static constexpr int kMaxLevels = 16;
   DevBuf levels[kMaxLevels];
@@ -269,7 +272,7 @@ int upload(rt_hip_scene *s, const std::vector<T> &v, const T **out)
   if (v.empty()) return RT_HIP_OK;
   void *p = nullptr;
   HIP_TRY(hipMalloc(&p, v.size() * sizeof(T)));
-  s->allocs.push_back(p);
+  s->geo->allocs.push_back(p);
   HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   *out = (const T *)p;
   return RT_HIP_OK;
@@ -290,10 +293,10 @@ int upload(rt_hip_scene *s, const std::vector<T> &v, const T **out)
 
 // diagnostic only (collect_stats builds of the kernels): start/end wall-clock stamp of every wave
 #define RT_MAX_STAMPS 65536
-__device__ unsigned long long g_stamps[2 * RT_MAX_STAMPS];
-__device__ __forceinline__ void stamp(unsigned int wave, int which)
+__device__ unsigned long long g_stamps[4 * RT_MAX_STAMPS];   // [kernel: 0 k_shadow, 1 k_primary][wave][start, end]
+__device__ __forceinline__ void stamp(unsigned int wave, int which, int kernel = 0)
 {
-  if ((threadIdx.x & 63) == 0 && wave < RT_MAX_STAMPS) g_stamps[2 * wave + which] = wall_clock64();
+  if ((threadIdx.x & 63) == 0 && wave < RT_MAX_STAMPS) g_stamps[2 * RT_MAX_STAMPS * kernel + 2 * wave + which] = wall_clock64();
 }
 #ifdef RT_TIMERS
 extern "C" int rt_hip_debug_read_timers(unsigned long long *out, int reset)
@@ -308,6 +311,12 @@ extern "C" int rt_hip_debug_read_stamps(unsigned long long *out, size_t n_waves)
 {
   if (n_waves > RT_MAX_STAMPS) n_waves = RT_MAX_STAMPS;
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n_waves * 16, 0, hipMemcpyDeviceToHost));
+  return RT_HIP_OK;
+}
+extern "C" int rt_hip_debug_read_stamps2(unsigned long long *out, size_t n_waves, int kernel)
+{
+  if (n_waves > RT_MAX_STAMPS) n_waves = RT_MAX_STAMPS;
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n_waves * 16, (size_t)kernel * 16 * RT_MAX_STAMPS, hipMemcpyDeviceToHost));
   return RT_HIP_OK;
 }
 
@@ -479,6 +488,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_primary(DevScene sc, 
   const bool active = (s_local < A.n_samples) && (tx < A.tiles_x) && (ty < A.tiles_y) && (h < (unsigned)A.cam.W) && (v < (unsigned)A.cam.H) &&
                       (p >= A.pixel_first) && (p < A.pixel_first + A.pixel_count);
   Stats st{};
+#ifdef RT_STAMPS
+  stamp(wave, 0, 1);
+#endif
   const uint32_t sample = A.sample_first + s_local;
   // curPt = startPt - left*(h/res) - up*(v/res), Camera.h:65
   V3 cur = A.cam.start - A.cam.left * (double(h) / double(A.cam.res)) - A.cam.up * (double(v) / double(A.cam.res));
@@ -500,6 +512,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_primary(DevScene sc, 
     nd.pixel = (uint32_t)p; nd.sample = sample; nd.path = 1;
     nd.child_refr = -1; nd.child_refl = -1; nd.w_refr = 0; nd.w_refl = 0;
   }
+#ifdef RT_STAMPS
+  stamp(wave, 1, 1);
+#endif
   if (shadow_flags) {
     // will this wave's shadow pass meet the tree?  (first light only: it orders work, nothing else)
     bool heavy = false;
@@ -758,7 +773,7 @@ extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
 {
   if (!s) return RT_HIP_OK;
   if (s->ctx) (void)hipSetDevice(s->ctx->device);
-  for (void *p : s->allocs) (void)hipFree(p);
+  s->geo.reset();
   for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &b : s->levels) b.release();
   s->counter.release(); s->staging.release(); s->lum.release(); s->order.release();
@@ -876,6 +891,19 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   D.n_root_objs = (int32_t)root_objs.size(); D.n_objects = (int32_t)d->n_objects; D.n_lights = (int32_t)d->n_lights;
   D.ambient = d->ambient; D.coord_scale = cs;
   s->n_nodes = (uint32_t)B.pairs.size(); s->n_leaves = B.n_leaves; s->n_cull = B.n_recs; s->max_depth = B.max_depth;
+  *out = s;
+  return RT_HIP_OK;
+}
+
+// A second handle on the same scene: the geometry in HBM is shared, the render workspace (level arrays,
+// luminosities, work order, counters) is its own, so that the two handles can render at the same time on
+// two streams ("frames in flight": the draining tail of one frame's kernels is filled by the next frame).
+extern "C" int rt_hip_scene_share(rt_hip_scene *src, rt_hip_scene **out)
+{
+  if (!src || !out) return fail(RT_HIP_EINVAL, "NULL argument");
+  rt_hip_scene *s = new rt_hip_scene();
+  s->ctx = src->ctx; s->dev = src->dev; s->geo = src->geo;
+  s->n_nodes = src->n_nodes; s->n_leaves = src->n_leaves; s->n_cull = src->n_cull; s->max_depth = src->max_depth;
   *out = s;
   return RT_HIP_OK;
 }

@@ -184,6 +184,34 @@ def test_pixel_shards_reassemble(ctx):
     assert (np.concatenate(parts) == full).all()
 
 
+def test_shared_handles_render_concurrently(ctx):
+    """rt_hip_scene_share: two handles on one geometry rendering at the same time on two streams give
+    the frames the single handle gives (bit-identical), also after the first handle is used again"""
+    import torch
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_heightfield(96)
+    cams = [rta.Camera(**dict(scenes.C2_CAMERA, res=25)), rta.Camera(**dict(scenes.C2_CAMERA, res=25, view=(-12.5, -8.5, 7), eye=(12.5, 8.5, -7), left=(8.5, -12.5, 0)))]
+    n = cams[0].width * cams[0].height
+    p = rta.Params(background=(200, 200, 200))
+    ref = []
+    for cam in cams:
+        out = np.zeros((n, 3))
+        rta.check(rta.hip.rt_hip_render_whitted(g.device(ctx), cam.raw, p, out.ctypes.data, None))
+        ref.append(out)
+    sh = g.share(ctx)
+    handles = [g.device(ctx), sh.raw]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    bufs = [torch.zeros((n, 3), dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in range(2):
+            rta.check(rta.hip.rt_hip_render_whitted_dev(handles[k], cams[k].raw, p, bufs[k].data_ptr(), None, streams[k].cuda_stream))
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert (bufs[k].cpu().numpy() == ref[k]).all()
+    del sh
+
+
 def test_c2_full_size_heightfield(ctx):
     """BASELINE configs[1] at full size (1,002,528 triangles, 1920x1080): hit ids on the 8-pixel grid
     (32,400 rays) and radiance (primary + shadow) on three full image rows against the oracle."""
