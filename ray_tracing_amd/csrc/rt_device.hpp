@@ -317,12 +317,14 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
         }
         RT_TM(3)
         const LeafRec *recs = (const LeafRec *)(lds->leaf + 64);
+        unsigned other = 0u;                       // records of kind 2 (spheres ...): exact test after the loop
 #ifdef RT_UNROLL
 #pragma unroll RT_UNROLL
 #endif
         for (int i = 0; i < nrec; i++) {
           const LeafRec &c = recs[i];
           const bool lane_on = want && !(ANY && found);
+          if (ANY && __ballot(lane_on) == 0ull) break;        // every interested ray of the wave is occluded
           if (STATS) { if (lane_on) st.prim_tests++; if ((threadIdx.x & 63) == 0) st.wave_prims++; }
           // all cull fields in one batch of LDS reads (no short-circuit: each would cost another round trip)
           const double n0 = c.n[0], n1 = c.n[1], n2 = c.n[2], dpl = c.dpl;
@@ -330,6 +332,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           const double G0 = c.G[0], G1 = c.G[1], G2 = c.G[2], g0 = c.g0;
           const double bsum = c.bsum;
           const int kind = uni(c.kind), prim = uni(c.prim_id);     // same LDS batch as the cull fields
+          other |= (kind == 2) ? (1u << i) : 0u;
           // ---- cull (explicit FMAs: this part only has to be conservative) ----
           const double g = fma(r.d.z, n2, fma(r.d.y, n1, r.d.x * n0));
           const double on = fma(r.o.z, n2, fma(r.o.y, n1, r.o.x * n0));
@@ -340,14 +343,12 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           const double be = fma(pz, B2, fma(py, B1, fma(px, B0, b0)));
           const double ga = fma(pz, G2, fma(py, G1, fma(px, G0, g0)));
           const double m = fma(r.mscale, bsum, 1e-6);
+          const bool tri = lane_on & (kind != 2);
           const bool untrusted = !(fabs(g) >= r.gmin) | (kind == 1);      // also catches NaN
           const bool inside = (tc > kEps - r.tlow * fabs(rg)) & (tc < r.bound + r.tmargin) & (be > -m) & (ga > -m) & (be + ga < 1.0 + m);
-          if (kind == 2) {                          // sphere etc.: exact test only (wave-uniform, rare)
-            if (STATS && lane_on) st.exact_tests++;
-            confirmed(lane_on ? leaf_other_t(sc, prim, r.o, r.d) : kMiss, prim, lane_on);
-          } else if (DEFER) {
-            if (lane_on & untrusted) D.redo = true;
-            if (lane_on & inside & !untrusted) {
+          if (DEFER) {
+            if (tri & untrusted) D.redo = true;
+            if (tri & inside & !untrusted) {
               if (ANY) {
                 // may this survivor occlude?  f(t) = Dot(o - X, ref - X), X = o + d t (Scene.h:449)
                 bool maybe = true;
@@ -361,7 +362,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
               }
             }
           } else {
-            const bool pass = lane_on & (untrusted | inside);
+            const bool pass = tri & (untrusted | inside);
             if (pass) {
               if (STATS) st.exact_tests++;
               const TriExact &T = sc.tri_exact[uni(c.tri_idx)];
@@ -370,6 +371,13 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
               confirmed(t, prim, true);
             }
           }
+        }
+        while (other) {                             // sphere etc.: exact test only (wave-uniform, rare)
+          const int i = __builtin_ctz(other); other &= other - 1u;
+          const int prim = uni(recs[i].prim_id);
+          const bool lane_on = want && !(ANY && found);
+          if (STATS && lane_on) st.exact_tests++;
+          confirmed(lane_on ? leaf_other_t(sc, prim, r.o, r.d) : kMiss, prim, lane_on);
         }
         // the next chunk overwrites the LDS image: all reads above are complete (values consumed)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
