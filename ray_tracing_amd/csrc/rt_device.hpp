@@ -94,9 +94,12 @@ constexpr double kGMin = 1e-5;     // |d.n| below this: skip the cull, go to the
 #define RT_STACK_DEPTH 64
 
 // per-wave LDS: the node stack and the staged leaf chunk
+struct RayLds { double o[3], d[3], bound, pad; };    // 64 B: what a lane needs to cull a record for ANOTHER lane's ray
 struct WaveLds {
   alignas(16) unsigned char leaf[RT_CHUNK_BYTES];
+  alignas(16) RayLds rays[64];
   ChildRef stack[RT_STACK_DEPTH];
+  unsigned int slot[64];                             // rank among the interested rays of a leaf -> lane
 };
 
 // uniform (scalar) copy of a value that is known to be the same in all lanes
@@ -174,6 +177,10 @@ __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_
   r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   r.bound = kMiss; r.best_t = kMiss; r.best_id = -1;
   double os = dmax(dmax(fabs(o.x), fabs(o.y)), fabs(o.z));
+  // one scale for the whole wave (the largest): in the redistributed cull a lane tests records for another lane's ray
+  for (int off = 32; off > 0; off >>= 1) os = dmax(os, __shfl_xor(os, off, 64));
+  { const unsigned long long b = __double_as_longlong(os);
+    os = __longlong_as_double(((unsigned long long)(unsigned)uni((int)(b >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned)b)); }
   double s = 1.0 + coord_scale + os;
   r.tmargin = 1e-6 * s;
   r.mscale = 1e-8 * s;
@@ -274,6 +281,10 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
   int sp = 0;
   ChildRef cur = sc.root;
   bool have = true;                                // `cur` holds the next node (the near child); else pop
+  if constexpr (DEFER) {                           // this wave's rays, for the redistributed cull (LDS is in order per wave)
+    RayLds &me = lds->rays[threadIdx.x & 63];
+    me.o[0] = r.o.x; me.o[1] = r.o.y; me.o[2] = r.o.z; me.d[0] = r.d.x; me.d[1] = r.d.y; me.d[2] = r.d.z; me.bound = r.bound; me.pad = 0.0;
+  }
   RT_TM_DECL
   while (true) {
     if (!have) {
@@ -317,6 +328,95 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
         }
         RT_TM(3)
         const LeafRec *recs = (const LeafRec *)(lds->leaf + 64);
+        if constexpr (DEFER) {
+          // ---- redistributed cull.  Typically ~1/6 of the wave's rays want a given leaf, so instead of all 64
+          // lanes stepping through every record with most of them idle, the n interested rays x nrec records are
+          // dealt out over the lanes: lane L culls record (base + L / n) for the ray of rank (L % n), whose
+          // origin/direction/bound it gathers from LDS.  Survivors (rare) are handed back to the owning lane,
+          // in record order per ray, which then does exactly what the broadcast loop did. ----
+          const unsigned int lane = threadIdx.x & 63;
+          const unsigned long long Wm = __ballot(want);
+          const int n = __popcll(Wm);
+          const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(Wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Wm, 0u));
+          if (want) lds->slot[rank] = lane;
+          // q = L / n, j = L % n through a 16-bit reciprocal (exact for L < 64, n <= 64: checked exhaustively in tests)
+          const unsigned int magic = (unsigned int)uni((int)((unsigned int)(65536.0f * __builtin_amdgcn_rcpf((float)n)) + 2u));
+          const unsigned int q = (lane * magic) >> 16, j = lane - q * (unsigned)n;
+          const int S = (int)((64u * magic) >> 16);          // records in flight per step = 64 / n
+          const bool lane_used = (int)q < S;
+          const unsigned int src = lds->slot[j];
+          const RayLds &gr = lds->rays[src];
+          const double gox = gr.o[0], goy = gr.o[1], goz = gr.o[2], gdx = gr.d[0], gdy = gr.d[1], gdz = gr.d[2], gbound = gr.bound;
+          if (STATS && (threadIdx.x & 63) == 0) st.wave_prims += nrec;
+          unsigned other = 0u;                       // records of kind 2 (spheres ...): exact test after the loop
+          for (int b0i = 0; b0i < nrec; b0i += S) {
+            if (ANY && __ballot(want && !found) == 0ull) break;      // every interested ray of the wave is occluded
+            const int rec = b0i + (int)q;
+            const bool valid = lane_used && rec < nrec;
+            const LeafRec &c = recs[valid ? rec : 0];
+            if (STATS && valid) st.prim_tests++;
+            const double n0 = c.n[0], n1 = c.n[1], n2 = c.n[2], dpl = c.dpl;
+            const double B0 = c.B[0], B1 = c.B[1], B2 = c.B[2], b0 = c.b0;
+            const double G0 = c.G[0], G1 = c.G[1], G2 = c.G[2], g0 = c.g0;
+            const double bsum = c.bsum;
+            const int kind = c.kind, prim = c.prim_id;
+            // ---- cull (explicit FMAs: this part only has to be conservative) ----
+            const double g = fma(gdz, n2, fma(gdy, n1, gdx * n0));
+            const double on = fma(goz, n2, fma(goy, n1, gox * n0));
+            double rg = __builtin_amdgcn_rcp(g);
+            rg = fma(fma(-g, rg, 1.0), rg, rg);       // one Newton step: ~2^-50 relative
+            const double tc = (dpl - on) * rg;
+            const double px = fma(gdx, tc, gox), py = fma(gdy, tc, goy), pz = fma(gdz, tc, goz);
+            const double be = fma(pz, B2, fma(py, B1, fma(px, B0, b0)));
+            const double ga = fma(pz, G2, fma(py, G1, fma(px, G0, g0)));
+            const double m = fma(r.mscale, bsum, 1e-6);
+            const bool untrusted = !(fabs(g) >= r.gmin) | (kind == 1);      // also catches NaN
+            const bool inside = (tc > kEps - r.tlow * fabs(rg)) & (tc < gbound + r.tmargin) & (be > -m) & (ga > -m) & (be + ga < 1.0 + m);
+            // kind-2 records: remember their index (one lane per record speaks)
+            unsigned long long om = __ballot(valid & (kind == 2) & (j == 0u));
+            while (om) { const int L = __builtin_ctzll(om); om &= om - 1ull; other |= 1u << (b0i + (int)(((unsigned)L * magic) >> 16)); }
+            // ---- events back to the owners, ascending lane = ascending record per ray ----
+            unsigned long long ev = __ballot(valid & (kind != 2) & (untrusted | inside));
+            while (ev) {
+              const int L = __builtin_ctzll(ev); ev &= ev - 1ull;
+              const unsigned int owner = (unsigned int)__builtin_amdgcn_readlane((int)src, L);
+              const int eprim = __builtin_amdgcn_readlane(prim, L);
+              const int eun = __builtin_amdgcn_readlane(untrusted ? 1 : 0, L);
+              const unsigned long long tbits = __double_as_longlong(tc);
+              const double etc = __longlong_as_double(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(tbits >> 32), L) << 32) |
+                                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)tbits, L));
+              if (lane == owner && !(ANY && found)) {
+                if (eun) D.redo = true;
+                else if (etc < r.bound + r.tmargin) {          // the owner's current bound (the gathered one may be older)
+                  if (ANY) {
+                    // may this survivor occlude?  f(t) = Dot(o - X, ref - X), X = o + d t (Scene.h:449)
+                    bool maybe = true;
+                    if (has_ref) {
+                      V3 X = mk(fma(r.d.x, etc, r.o.x), fma(r.d.y, etc, r.o.y), fma(r.d.z, etc, r.o.z));
+                      maybe = dot(r.o - X, ref - X) < -kEps + fmargin;
+                    }
+                    if (maybe) { found = true; D.c1_id = eprim; D.c1_t = etc; }
+                  } else if (eprim != D.c1_id && eprim != D.c2_id) {
+                    if (etc < D.c1_t) { D.c3_t = fmin(D.c3_t, D.c2_t); D.c2_t = D.c1_t; D.c2_id = D.c1_id; D.c1_t = etc; D.c1_id = eprim; }
+                    else if (etc < D.c2_t) { D.c3_t = fmin(D.c3_t, D.c2_t); D.c2_t = etc; D.c2_id = eprim; }
+                    else D.c3_t = fmin(D.c3_t, etc);
+                    r.bound = fmin(r.bound, D.c1_t + 2.0 * r.tmargin);
+                    lds->rays[lane].bound = r.bound;
+                  }
+                }
+              }
+            }
+          }
+          while (other) {                             // sphere etc.: exact test only (wave-uniform, rare)
+            const int i = __builtin_ctz(other); other &= other - 1u;
+            const int prim = uni(recs[i].prim_id);
+            const bool lane_on = want && !(ANY && found);
+            if (STATS && lane_on) st.exact_tests++;
+            const double bt = r.best_t;
+            confirmed(lane_on ? leaf_other_t(sc, prim, r.o, r.d) : kMiss, prim, lane_on);
+            if (!ANY && r.best_t != bt) lds->rays[lane].bound = r.bound;
+          }
+        } else {
         unsigned other = 0u;                       // records of kind 2 (spheres ...): exact test after the loop
 #ifdef RT_UNROLL
 #pragma unroll RT_UNROLL
@@ -378,6 +478,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           const bool lane_on = want && !(ANY && found);
           if (STATS && lane_on) st.exact_tests++;
           confirmed(lane_on ? leaf_other_t(sc, prim, r.o, r.d) : kMiss, prim, lane_on);
+        }
         }
         // the next chunk overwrites the LDS image: all reads above are complete (values consumed)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
