@@ -447,26 +447,37 @@ __global__ void __launch_bounds__(256) k_classify(DevScene sc, RenderArgs A, uns
   flags[w] = heavy ? 1 : 0;
 }
 
-// single block: stable partition of the wave indices by flag
+// single block: stable partition of the wave indices by flag, 1024 indices per step (ballot + 16 wave totals)
 __global__ void __launch_bounds__(1024) k_order(const unsigned char *flags, unsigned int n, unsigned int *order)
 {
-  __shared__ unsigned int s_cnt[1024];
-  const unsigned int t = threadIdx.x, per = (n + 1023) / 1024;
-  const unsigned int lo = min(n, t * per), hi = min(n, lo + per);
+  __shared__ unsigned int s_w[16];
+  const unsigned int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // heavy total
   unsigned int c = 0;
-  for (unsigned int i = lo; i < hi; i++) c += flags[i] ? 1u : 0u;
-  s_cnt[t] = c;
+  for (unsigned int i = t; i < n; i += 1024) c += flags[i] ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if (lane == 0) s_w[w] = c;
   __syncthreads();
-  for (unsigned int off = 1; off < 1024; off <<= 1) {      // inclusive scan
-    unsigned int v = (t >= off) ? s_cnt[t - off] : 0u;
+  unsigned int total = 0;
+  for (int k = 0; k < 16; k++) total += s_w[k];
+  __syncthreads();
+  unsigned int hbase = 0, lbase = total;
+  for (unsigned int base = 0; base < n; base += 1024) {
+    const unsigned int i = base + t;
+    const bool valid = i < n;
+    const bool f = valid && flags[i];
+    const unsigned long long mask = __ballot(f);
+    if (lane == 0) s_w[w] = (unsigned int)__popcll(mask);
     __syncthreads();
-    s_cnt[t] += v;
+    unsigned int before = 0, tile_total = 0;
+    for (unsigned int k = 0; k < 16; k++) { const unsigned int v = s_w[k]; if (k < w) before += v; tile_total += v; }
     __syncthreads();
+    const unsigned int hrank = before + (unsigned int)__popcll(mask & below);     // heavy entries of this step before me
+    if (valid) order[f ? (hbase + hrank) : (lbase + (t - hrank))] = i;
+    const unsigned int in_tile = (n - base < 1024u) ? (n - base) : 1024u;
+    hbase += tile_total; lbase += in_tile - tile_total;
   }
-  const unsigned int total = s_cnt[1023];
-  unsigned int hpos = s_cnt[t] - c;                         // heavy waves before this chunk
-  unsigned int lpos = total + (lo - hpos);                  // light waves go after all heavy ones
-  for (unsigned int i = lo; i < hi; i++) { if (flags[i]) order[hpos++] = i; else order[lpos++] = i; }
 }
 
 // level 0: camera / lens ray generation (Camera.h:65-67, 189-190) + closest hit, one 8x8 pixel tile per wave
@@ -605,8 +616,11 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_shadow(DevScene sc, R
 
 // RayTracer (RayTracer.h:8-55) for one level of the ray tree: local illumination from the luminosities of
 // the shadow pass and generation of the refracted / reflected child rays into the next level's queue.
+// direct_rgb != NULL (level 0 of a depth-1 frame, one sample per pixel): the colour is final, so it goes straight
+// to the frame (Camera.h:69) and the separate resolve pass over the level array is skipped.
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, PathNode *nodes, unsigned int n, int depth_left,
-                                                     const double *lum, PathNode *next, unsigned int next_cap, RenderCounters *cnt)
+                                                     const double *lum, PathNode *next, unsigned int next_cap, RenderCounters *cnt,
+                                                     double *direct_rgb, int32_t *direct_id)
 {
   const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
   const bool in_range = i < n;
@@ -671,6 +685,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, P
       q.id = -1; q.t = kMiss; q.child_refr = -1; q.child_refl = -1; q.w_refr = 0; q.w_refl = 0;
       child_refl = (int)k;
     }
+  }
+  if (direct_rgb) {
+    if (in_range && nd.weight > 0.0) {          // padding lanes of edge tiles carry weight 0
+      const uint64_t q = (uint64_t)nd.pixel - A.pixel_first;
+      direct_rgb[3 * q] = c.r; direct_rgb[3 * q + 1] = c.g; direct_rgb[3 * q + 2] = c.b;
+      if (direct_id) direct_id[q] = nd.id;
+    }
+    return;
   }
   if (in_range) {
     PathNode &w = nodes[i];
@@ -1039,7 +1061,7 @@ extern "C" int rt_hip_camera_size(const rt_hip_camera *cam, int *w, int *h)
 }
 
 // the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
-static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st)
+static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, double *direct_rgb = nullptr, int32_t *direct_id = nullptr)
 {
   const uint64_t n_waves = (uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * A.n_samples;
   const uint64_t n0 = n_waves * 64;      // level 0 in tile order, edge tiles padded
@@ -1104,7 +1126,9 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     }
     {
       ProfScope ps(s, RT_HIP_K_SHADE, st);
-      hipLaunchKernelGGL(k_shade, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt);
+      const bool direct = direct_rgb && lv == 0 && depth == 1;
+      hipLaunchKernelGGL(k_shade, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt,
+                         direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr);
     }
     HIP_TRY(hipGetLastError());
     if (depth_left > 1) {
@@ -1154,9 +1178,12 @@ extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *c
   rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
   s->last_rays = 0; s->last_shadow = 0;
-  rc = run_levels(s, A, P->collect_stats != 0, st); if (rc) return rc;
-  { ProfScope ps(s, RT_HIP_K_RESOLVE, st);
-  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, 1.0, 0, d_rgb, d_prim_id); }
+  const bool direct = A.cam.depth <= 1;     // a depth-1 frame is final after level 0: k_shade writes it
+  rc = run_levels(s, A, P->collect_stats != 0, st, direct ? d_rgb : nullptr, direct ? d_prim_id : nullptr); if (rc) return rc;
+  if (!direct) {
+    ProfScope ps(s, RT_HIP_K_RESOLVE, st);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, 1.0, 0, d_rgb, d_prim_id);
+  }
   HIP_TRY(hipGetLastError());
   return RT_HIP_OK;
 }
