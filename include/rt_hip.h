@@ -75,6 +75,11 @@ typedef struct { double v[3][3]; double vn[3][3]; int32_t has_vn; int32_t reserv
 typedef struct { double p0[3]; double n[3]; } rt_hip_plane;              /* CInftyPlane; n already unitized (Object.h:686) */
 typedef struct { double c[3]; double r; } rt_hip_sphere;                 /* CSphere, Object.h:246-247 */
 typedef struct { double p0[3]; double n[3]; double r; } rt_hip_circle;   /* CCircle; n already unitized (Object.h:652) */
+/* CBezierObject (Object.h:1041-1063): bicubic patch, controlPts[i][j] (Bezier.h:96) + center */
+typedef struct { double ctrl[4][4][3]; double center[3]; } rt_hip_bezier;                         /* 408 B */
+/* CRotationalObject (Object.h:791-808): Bezier profile curve (u = radius, v = height; 2..8 control points,
+ * Bezier.h:13), rotated about the z axis through center; uSampleNum Newton seeds over [0, uRange] */
+typedef struct { double profile[8][2]; double center[3]; double u_range; int32_t n_profile; int32_t u_sample_num; } rt_hip_rotational; /* 168 B */
 /* CMaterial, Material.h:33-42 */
 typedef struct { double reflW, refrW, RI, diff, spec, shiness, emissive, ambient; } rt_hip_material;
 /* CPointLight / CParallelLight / CAreaLight (Light.h:48-124).  pos_or_dir: position, or the
@@ -107,6 +112,8 @@ typedef struct {
   uint32_t n_nodes;     const rt_hip_node *nodes;      /* nodes[0] = root */
   uint32_t n_refs;      const uint32_t    *refs;       /* leaf object lists, prim ids */
   uint32_t n_root_objects; const uint32_t *root_objects; /* bspTree.root->objects after the build (BSPTree.h:104-105) */
+  uint32_t n_beziers;     const rt_hip_bezier     *beziers;
+  uint32_t n_rotationals; const rt_hip_rotational *rotationals;
 } rt_hip_scene_desc;
 
 /* CCamera constructor arguments (Camera.h:17-18) */

@@ -413,13 +413,203 @@ static v3 circle_first_inter_pt(const obj_t *o, ray_t ray)  /* Object.h:667-678 
   return pt;
 }
 
+
+/* ------------------------------------------------------------------ Bezier curve / surfaces (Bezier.h) */
+static inline v2 p2_add(v2 a, v2 b) { v2 r = {a.u + b.u, a.v + b.v}; return r; }       /* Geometry.h:149 */
+static inline v2 p2_sub(v2 a, v2 b) { v2 r = {a.u - b.u, a.v - b.v}; return r; }       /* :150 */
+static inline v2 p2_mul(v2 a, double l) { v2 r = {a.u * l, a.v * l}; return r; }       /* :151 */
+static inline v2 p2_unitize(v2 a)                                                      /* :219-225 */
+{
+  v2 z = {0, 0};
+  if (v2_eq(a, z) || v2_eq(a, infty_pt2())) return infty_pt2();
+  double len = sqrt((a.u - 0) * (a.u - 0) + (a.v - 0) * (a.v - 0));                    /* Len() = Dist(*this, (0,0)), :232-236 */
+  v2 r = {a.u / len, a.v / len};
+  return r;
+}
+/* CBezierCurve::Point2D(t, i, deg), de Casteljau by recursion (Bezier.h:28-34) */
+static v2 curve_pt(const obj_t *o, double t, int i, int deg)
+{
+  if (deg == 0) return o->prof[i];
+  return p2_add(p2_mul(curve_pt(o, t, i, deg - 1), 1 - t), p2_mul(curve_pt(o, t, i + 1, deg - 1), t));
+}
+static v2 curve_point2d(const obj_t *o, double t) { return curve_pt(o, t, 0, o->n_prof - 1); }       /* :16 */
+static v2 curve_tan(const obj_t *o, double t)                                                        /* :36-39 */
+{ int deg = o->n_prof - 1; return p2_mul(p2_sub(curve_pt(o, t, 1, deg - 1), curve_pt(o, t, 0, deg - 1)), deg); }
+static v2 curve_norm(const obj_t *o, double t)                                                       /* :41-45 */
+{ v2 tv = curve_tan(o, t); v2 n = {tv.v, -tv.u}; return p2_unitize(n); }
+/* CRotationalSurface (Bezier.h:65-87) */
+static v3 rot_point(const obj_t *o, double t, double th) { v2 p = curve_point2d(o, t); return V3(p.u * cos(th), p.u * sin(th), p.v); }
+static v3 rot_norm(const obj_t *o, double t, double th) { v2 r = curve_norm(o, t); return v_unitize(V3(r.u * cos(th), r.u * sin(th), r.v)); }
+static v3 rot_ds_dt(const obj_t *o, double t, double th) { v2 d = curve_tan(o, t); return V3(cos(th) * d.u, sin(th) * d.u, d.v); }
+static v3 rot_ds_dth(const obj_t *o, double t, double th) { v2 p = curve_point2d(o, t); return V3(-(p.u) * sin(th), p.u * cos(th), 0); }
+/* CBezierSurface::Point3D(u, v, i, j, k, l), m = n = 3 (Bezier.h:116-128) */
+static v3 surf_pt(const obj_t *o, double u, double v, int i, int j, int k, int l)
+{
+  const int m = 3, n = 3;
+  if (k == 0 && l == 0) return o->ctrl[i][j];
+  else if (l == 0) return v_add(v_mul(surf_pt(o, u, v, i, j, k - 1, 0), 1 - u), v_mul(surf_pt(o, u, v, i + 1, j, k - 1, 0), u));
+  else if (k == m) return v_add(v_mul(surf_pt(o, u, v, 0, j, m, l - 1), 1 - v), v_mul(surf_pt(o, u, v, 0, j + 1, m, l - 1), v));
+  else if (k == 0) return v_add(v_mul(surf_pt(o, u, v, i, j, 0, l - 1), 1 - v), v_mul(surf_pt(o, u, v, i, j + 1, 0, l - 1), v));
+  else if (l == n) return v_add(v_mul(surf_pt(o, u, v, i, 0, k - 1, n), 1 - u), v_mul(surf_pt(o, u, v, i + 1, 0, k - 1, n), u));
+  return infty_pt();   /* not reached for m = n = 3 */
+}
+static v3 surf_point(const obj_t *o, double u, double v) { return surf_pt(o, u, v, 0, 0, 3, 3); }     /* :98 */
+static v3 surf_du(const obj_t *o, double u, double v)                                                 /* :130-133 */
+{ return v_mul(v_sub(surf_pt(o, u, v, 1, 0, 2, 3), surf_pt(o, u, v, 0, 0, 2, 3)), 3); }
+static v3 surf_dv(const obj_t *o, double u, double v)                                                 /* :135-138 */
+{ return v_mul(v_sub(surf_pt(o, u, v, 0, 1, 3, 2), surf_pt(o, u, v, 0, 0, 3, 2)), 3); }
+static v3 surf_norm(const obj_t *o, double u, double v) { return v_unitize(v_cross(surf_du(o, u, v), surf_dv(o, u, v))); }  /* :99 */
+
+static const int MAX_STEP_NUM = 10;           /* Object.h:831 */
+static const double MIN_STEP_LEN = 1e-8;      /* :832 (= eps) */
+static const double MAX_DEVIATION = 0.3;      /* :833 */
+
+/* CRotationalObject::t_v_Initial (Object.h:972-1037): seed (t, theta) from the plane / sphere through the profile point */
+static v2 rot_t_v_initial(const obj_t *o, double u, ray_t ray)
+{
+  v2 pt2 = curve_point2d(o, u);
+  v3 p0 = V3(o->center.x, o->center.y, o->center.z + pt2.v);
+  v3 n = V3(0, 0, 1);
+  double v = 0;
+  if (fabs(v_dot(n, ray.d)) < 0.1) {
+    v3 p = V3(0, 0, 0);
+    double t = 0;
+    v3 l = v_sub(p0, ray.o);
+    double tp = v_dot(l, ray.d);
+    double d2 = v_len2(l) - tp * tp;
+    if (d2 > pt2.u * pt2.u + EPS) return infty_pt2();
+    double t_prime = sqrt(pt2.u * pt2.u - d2);
+    if (v_len2(l) < pt2.u * pt2.u - EPS * 1000) { t = tp + t_prime; p = v_add(ray.o, v_mul(ray.d, t)); }
+    else if (v_len2(l) > pt2.u * pt2.u + EPS * 1000) {
+      t = tp - t_prime;
+      if (t > EPS) p = v_add(ray.o, v_mul(ray.d, t));
+      else return infty_pt2();
+    } else {
+      if (tp < EPS * 1000) return infty_pt2();
+      t = tp * 2; p = v_add(ray.o, v_mul(ray.d, tp * 2));
+    }
+    double cos_theta = v_sub(p, p0).x / v_len(v_sub(p, p0));
+    double theta = acos(cos_theta);
+    if (p.y > p0.y || (p.y == p0.y && p.x > p0.x)) v = theta; else v = 2 * PI_REF - theta;
+    v2 r = {t, v};
+    return r;
+  }
+  double D = -v_dot(p0, n);
+  double t = -(D + v_dot(n, ray.o)) / v_dot(n, ray.d);
+  v3 p = v_add(ray.o, v_mul(ray.d, t));
+  if (t < EPS) return infty_pt2();
+  double cos_theta = v_sub(p, p0).x / v_len(v_sub(p, p0));
+  double theta = acos(cos_theta);
+  if (p.y > p0.y || (p.y == p0.y && p.x > p0.x)) v = theta; else v = 2 * PI_REF - theta;
+  v2 r = {t, v};
+  return r;
+}
+
+/* CRotationalObject::FirstInterPt / _Unrecorded (Object.h:834-952); they differ in the t' threshold only */
+static hit_t rot_first_inter_pt(const obj_t *o, ray_t ray, int record)
+{
+  hit_t h; h.pt = infty_pt(); h.u = INFTY; h.v = INFTY;
+  if (v2_eq(box_collide(o->aabb, ray), infty_pt2())) return h;
+  double cur_u = INFTY, cur_v = INFTY, cur_t = INFTY;
+  int have = 0;
+  const double t_thr = record ? EPS * 10 : EPS * 5000;
+  double u_int = o->u_range / (double)o->u_sample_num;
+  for (int i = 0; i <= o->u_sample_num; i++) {
+    double u = i * u_int;
+    v2 tv = rot_t_v_initial(o, u, ray);
+    if (v2_eq(tv, infty_pt2())) continue;
+    double v = tv.v, t = tv.u;
+    v3 w = ray.d;
+    for (int step = 0; step < MAX_STEP_NUM; step++) {
+      v3 dPu = rot_ds_dt(o, u, v), dPv = rot_ds_dth(o, u, v);
+      double D = v_dot(w, v_cross(dPu, dPv));
+      v3 df = v_sub(v_add(o->center, rot_point(o, u, v)), v_add(ray.o, v_mul(ray.d, t)));
+      double t_p = t + v_dot(dPu, v_cross(dPv, df)) / D;
+      double u_p = u + v_dot(w, v_cross(dPv, df)) / D;
+      double v_p = v - v_dot(w, v_cross(dPu, df)) / D;
+      if (u_p < -MAX_DEVIATION || u_p > 1 + MAX_DEVIATION || t_p < -MAX_DEVIATION) break;
+      if (v_len2(V3(t_p - t, u_p - u, v_p - v)) < MIN_STEP_LEN && t_p > t_thr && 0 < u_p && u_p < o->u_range) {
+        have = 1;
+        if (t_p < cur_t) { cur_u = u_p; cur_v = v_p; cur_t = t_p; break; }
+      }
+      u = u_p; v = v_p; t = t_p;
+    }
+  }
+  if (have) { h.pt = v_add(o->center, rot_point(o, cur_u, cur_v)); h.u = cur_u; h.v = cur_v; }
+  return h;
+}
+
+/* CBezierObject::FirstInterPt / _Unrecorded (Object.h:1087-1202): identical arithmetic */
+static hit_t bezier_first_inter_pt(const obj_t *o, ray_t ray)
+{
+  hit_t h; h.pt = infty_pt(); h.u = INFTY; h.v = INFTY;
+  double cur_u = INFTY, cur_v = INFTY, cur_t = INFTY;
+  int have = 0;
+  double u_int = 1 / (double)4, v_int = 1 / (double)4;       /* uSampleNum2 = vSampleNum2 = 4, :1085-1086 */
+  for (int i = 0; i <= 4; i++) {
+    for (int j = 0; j <= 4; j++) {
+      double u = i * u_int, v = j * v_int;
+      double t = v_dist(v_add(surf_point(o, u, v), o->center), ray.o);
+      v3 w = ray.d;
+      for (int step = 0; step < MAX_STEP_NUM; step++) {
+        v3 dPu = surf_du(o, u, v), dPv = surf_dv(o, u, v);
+        double D = v_dot(w, v_cross(dPu, dPv));
+        v3 df = v_sub(v_add(o->center, surf_point(o, u, v)), v_add(ray.o, v_mul(ray.d, t)));
+        double t_p = t + v_dot(dPu, v_cross(dPv, df)) / D;
+        double u_p = u + v_dot(w, v_cross(dPv, df)) / D;
+        double v_p = v - v_dot(w, v_cross(dPu, df)) / D;
+        if (u_p < -MAX_DEVIATION || u_p > 1 + MAX_DEVIATION || v_p < -MAX_DEVIATION || v_p > 1 + MAX_DEVIATION || t_p < -MAX_DEVIATION) break;
+        if (v_len2(V3(t_p - t, u_p - u, v_p - v)) < MIN_STEP_LEN && t_p > EPS && 0 < u_p && u_p < 1 && 0 < v_p && v_p < 1) {
+          have = 1;
+          if (t_p < cur_t - EPS) { cur_u = u_p; cur_v = v_p; cur_t = t_p; break; }
+        }
+        u = u_p; v = v_p; t = t_p;
+      }
+    }
+  }
+  if (have) { h.pt = v_add(o->center, surf_point(o, cur_u, cur_v)); h.u = cur_u; h.v = cur_v; }
+  return h;
+}
+
+int orc_add_bezier(orc_scene *s, const double ctrl[48], const double center[3], const double mat[8], const double col[3])
+{                                               /* Object.h:1075-1083, AABB :1204-1227 */
+  obj_t *o = new_obj(s, ORC_BEZIER, mat, col);
+  o->center = V3(center[0], center[1], center[2]);
+  v3 mn = V3(INFTY, INFTY, INFTY), mx = V3(-INFTY, -INFTY, -INFTY);
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+    v3 c = V3(ctrl[(i * 4 + j) * 3], ctrl[(i * 4 + j) * 3 + 1], ctrl[(i * 4 + j) * 3 + 2]);
+    o->ctrl[i][j] = c;
+    mn = V3(dmin(mn.x, c.x), dmin(mn.y, c.y), dmin(mn.z, c.z));
+    mx = V3(dmax(mx.x, c.x), dmax(mx.y, c.y), dmax(mx.z, c.z));
+  }
+  o->aabb.mn = v_add(mn, o->center); o->aabb.mx = v_add(mx, o->center);
+  return s->n_objs - 1;
+}
+
+int orc_add_rotational(orc_scene *s, const double *prof, int n_prof, const double center[3], int u_sample_num, double u_range,
+                       const double mat[8], const double col[3])
+{                                               /* Object.h:818-829, AABB :954-970 */
+  if (n_prof < 2 || n_prof > 8 || u_sample_num < 1) return -1;
+  obj_t *o = new_obj(s, ORC_ROTATIONAL, mat, col);
+  o->center = V3(center[0], center[1], center[2]);
+  o->n_prof = n_prof; o->u_sample_num = u_sample_num; o->u_range = u_range;
+  double r = 0;
+  for (int i = 0; i < n_prof; i++) { o->prof[i].u = prof[2 * i]; o->prof[i].v = prof[2 * i + 1]; if (o->prof[i].u > r) r = o->prof[i].u; }
+  double z_max = o->center.z + dmax(o->prof[0].v, o->prof[n_prof - 1].v);
+  double z_min = o->center.z + dmin(o->prof[0].v, o->prof[n_prof - 1].v);
+  o->aabb.mn = V3(o->center.x - r - EPS, o->center.y - r - EPS, z_min - EPS);
+  o->aabb.mx = V3(o->center.x + r + EPS, o->center.y + r + EPS, z_max + EPS);
+  return s->n_objs - 1;
+}
+
 /* virtual FirstInterPt / FirstInterPt_Unrecorded dispatch (Object.h:37-38) */
 static hit_t obj_first_inter_pt(const obj_t *o, ray_t ray, int record)
 {
   hit_t h; h.u = INFTY; h.v = INFTY;
-  (void)record;
   if (tl_cnt) tl_cnt->prims++;
   switch (o->type) {
+    case ORC_BEZIER:      return bezier_first_inter_pt(o, ray);
+    case ORC_ROTATIONAL:  return rot_first_inter_pt(o, ray, record);
     case ORC_TRIANGLE:    h.pt = tri_first_inter_pt(o, ray); break;
     case ORC_SPHERE:      h.pt = sphere_first_inter_pt(o, ray); break;
     case ORC_INFTY_PLANE: h.pt = plane_first_inter_pt(o, ray); break;
@@ -432,8 +622,9 @@ static hit_t obj_first_inter_pt(const obj_t *o, ray_t ray, int record)
 /* ------------------------------------------------------------------ normals, reflect/refract, Fresnel */
 static v3 obj_initial_norm(const obj_t *o, v3 pt, double u, double v)
 {
-  (void)u; (void)v;
   switch (o->type) {
+    case ORC_BEZIER: return surf_norm(o, u, v);                                           /* Object.h:1049 */
+    case ORC_ROTATIONAL: return rot_norm(o, u, v);                                        /* Object.h:799 */
     case ORC_SPHERE: return v_unitize(v_sub(pt, o->c));                                   /* Object.h:239 */
     case ORC_TRIANGLE: {                                                                  /* Object.h:448-457 */
       if (!o->have_vn) return o->m_norm;

@@ -50,6 +50,11 @@ void orc_scene_free(orc_scene *s);
 int orc_add_sphere(orc_scene *s, const double c[3], double r, const double mat[8], const double col[3]);
 int orc_add_plane(orc_scene *s, const double p0[3], const double n[3], const double mat[8], const double col[3]);
 int orc_add_circle(orc_scene *s, const double p0[3], const double n[3], double r, const double mat[8], const double col[3]);
+/* CBezierObject(ctrl[4][4], center, ...), Object.h:1075; ctrl row-major [i][j][xyz] */
+int orc_add_bezier(orc_scene *s, const double ctrl[48], const double center[3], const double mat[8], const double col[3]);
+/* CRotationalObject(curve, center, ..., uSampleNum, uRange), Object.h:818; profile = n_prof (2..8) control points (u = radius, v = height) */
+int orc_add_rotational(orc_scene *s, const double *prof, int n_prof, const double center[3], int u_sample_num, double u_range,
+                       const double mat[8], const double col[3]);
 /* vn may be NULL (haveVertexNorm=false, Object.h:360-371) */
 int orc_add_triangle(orc_scene *s, const double v[9], const double vn[9], const double mat[8], const double col[3]);
 /* Scene.h:150-166 + Parser.h:35-82; returns number of triangles added or -1 */

@@ -89,6 +89,8 @@ host.rth_material_preset.argtypes = [C.c_int, d8]
 host.rth_add_sphere.argtypes = [_vp, d3, C.c_double, d8, d3]
 host.rth_add_plane.argtypes = [_vp, d3, d3, d8, d3]
 host.rth_add_circle.argtypes = [_vp, d3, d3, C.c_double, d8, d3]
+host.rth_add_bezier.argtypes = [_vp, _vp, d3, d8, d3]
+host.rth_add_rotational.argtypes = [_vp, _vp, C.c_int, d3, C.c_int, C.c_double, d8, d3]
 host.rth_add_triangle.argtypes = [_vp, _vp, _vp, d8, d3]
 host.rth_add_triangles.argtypes = [_vp, _vp, C.c_size_t, d8, d3]
 host.rth_read_obj_triangle.argtypes = [_vp, C.c_char_p, d3, C.c_double, d8, d3, C.POINTER(C.c_int)]
@@ -217,6 +219,18 @@ class Scene:
 
     def add_circle(self, p0, n, r, mat, colour):
         return host.rth_add_circle(self._h, d3(*p0), d3(*n), r, mat, d3(*colour))
+
+    def add_bezier(self, ctrl, center, mat, colour):
+        """CBezierObject: ctrl[4][4][3] control points + center"""
+        c = np.ascontiguousarray(ctrl, dtype=np.float64).reshape(48)
+        _chk_host(host.rth_add_bezier(self._h, c.ctypes.data, d3(*center), mat, d3(*colour)))
+        return self.num_objects - 1
+
+    def add_rotational(self, profile, center, u_sample_num, u_range, mat, colour):
+        """CRotationalObject: profile = Bezier control points (radius, height)"""
+        pr = np.ascontiguousarray(profile, dtype=np.float64).reshape(-1, 2)
+        _chk_host(host.rth_add_rotational(self._h, pr.ctypes.data, pr.shape[0], d3(*center), int(u_sample_num), float(u_range), mat, d3(*colour)))
+        return self.num_objects - 1
 
     def add_triangle(self, v, vn, mat, colour):
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(9)

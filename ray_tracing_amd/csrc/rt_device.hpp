@@ -17,6 +17,7 @@
 // Accepted hits therefore carry exactly the t the reference formula produces.
 #pragma once
 #include "rt_math.hpp"
+#include "rt_param.hpp"
 
 #ifndef RT_OBJ_INLINE
 #define RT_OBJ_INLINE __forceinline__   /* noinline was tried: the call ABI costs more registers than it saves */
@@ -77,6 +78,8 @@ struct DevScene {
   const int32_t *root_objs; int32_t n_root_objs;// bspTree.root->objects (infinite objects)
   const TriExact *tri_exact; const TriShade *tri_shade;
   const DPlane *planes; const DSphere *spheres; const DCircle *circles;
+  const DBezier *beziers; const DRotational *rotationals;
+  int32_t has_param;                            // the scene holds Bezier / rotational objects: kernels built with PARAM
   const uint8_t *obj_type; const uint32_t *obj_index; const uint32_t *obj_mat; const double *obj_colour;
   int32_t n_objects;
   const DMaterial *materials;
@@ -105,11 +108,15 @@ struct WaveLds {
 // uniform (scalar) copy of a value that is known to be the same in all lanes
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// ---- per-object exact test (CBaseObject::FirstInterPt dispatch, Object.h:37) --------------------
-__device__ RT_OBJ_INLINE double object_t(const DevScene &sc, int id, V3 o, V3 d)
+// ---- per-object exact test (CBaseObject::FirstInterPt / FirstInterPt_Unrecorded dispatch, Object.h:37-38) ----
+// PARAM = false: kernels for scenes without Bezier / rotational objects (their Newton code is not compiled in).
+// u, v: surface parameters of the hit (cur_u / cur_v, Object.h:805-808, 1059-1062), 1e8 for the other types.
+template <bool PARAM>
+__device__ RT_OBJ_INLINE double object_hit(const DevScene &sc, int id, V3 o, V3 d, bool record, double &u, double &v)
 {
   const int type = sc.obj_type[id];
   const uint32_t k = sc.obj_index[id];
+  u = kInfty; v = kInfty;
   if (type == 1) {        // RT_HIP_TRIANGLE
     const TriExact &T = sc.tri_exact[k];
     return tri_exact_t(mk(T.v0[0], T.v0[1], T.v0[2]), mk(T.v1[0], T.v1[1], T.v1[2]), mk(T.v2[0], T.v2[1], T.v2[2]),
@@ -124,8 +131,19 @@ __device__ RT_OBJ_INLINE double object_t(const DevScene &sc, int id, V3 o, V3 d)
     const DCircle &C = sc.circles[k];
     return circle_t(mk(C.p0[0], C.p0[1], C.p0[2]), mk(C.n[0], C.n[1], C.n[2]), C.r, o, d);
   }
+  if constexpr (PARAM) {
+    if (type == 6) {      // RT_HIP_BEZIER
+      ParamHit h = bezier_hit(sc.beziers[k], o, d);
+      u = h.u; v = h.v; return h.t;
+    } else if (type == 5) { // RT_HIP_ROTATIONAL
+      ParamHit h = rotational_hit(sc.rotationals[k], o, d, record);
+      u = h.u; v = h.v; return h.t;
+    }
+  }
   return kMiss;
 }
+__device__ RT_OBJ_INLINE double object_t(const DevScene &sc, int id, V3 o, V3 d)
+{ double u, v; return object_hit<false>(sc, id, o, d, true, u, v); }
 
 // The occlusion predicate of Scene.h:449 / Light.h:66,147: the hit X = o + d t lies between the
 // shaded point o and the reference point.  Without a reference point (parallel light,
@@ -162,6 +180,9 @@ struct RayState {
   double gmin;        // per-ray |d.n| threshold below which the cull is not trusted
   double tlow;        // scale of the margin of the t > eps test: tlow / |d.n|
   unsigned dsign;     // bit a set: d[a] >= 0 (near-child order of the packet, never results)
+  double best_u, best_v;            // surface parameters of the confirmed hit (PARAM kernels only)
+  int mb_id; double mb_t, mb_u, mb_v; // the last non-triangle leaf object tested and its result: the reference re-solves an
+                                      // object in every leaf that lists it (Scene.h:352), always with the same result
 };
 
 __device__ __forceinline__ double safe_inv(double x) { return (fabs(x) < 1e-30) ? ((x < 0) ? -1e30 : 1e30) : 1.0 / x; }
@@ -176,6 +197,7 @@ __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_
   r.o = o; r.d = d;
   r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   r.bound = kMiss; r.best_t = kMiss; r.best_id = -1;
+  r.best_u = kInfty; r.best_v = kInfty; r.mb_id = -1; r.mb_t = kMiss; r.mb_u = kInfty; r.mb_v = kInfty;
   double os = dmax(dmax(fabs(o.x), fabs(o.y)), fabs(o.z));
   // one scale for the whole wave (the largest): in the redistributed cull a lane tests records for another lane's ray
   for (int off = 32; off > 0; off >>= 1) os = dmax(os, __shfl_xor(os, off, 64));
@@ -231,11 +253,18 @@ __device__ __forceinline__ void stage_chunk(const unsigned char *src, unsigned c
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// exact test of a finite non-triangle object referenced by a leaf (today: spheres)
-__device__ __forceinline__ double leaf_other_t(const DevScene &sc, int id, V3 o, V3 d)
+// exact test of a finite non-triangle object referenced by a leaf (sphere, Bezier patch, surface of revolution),
+// through the per-ray mailbox
+template <bool PARAM>
+__device__ __forceinline__ double leaf_other_hit(const DevScene &sc, RayState &r, int id, bool record, double &u, double &v)
 {
-  const DSphere &S = sc.spheres[sc.obj_index[id]];
-  return sphere_t(mk(S.c[0], S.c[1], S.c[2]), S.r, o, d);
+  if constexpr (!PARAM) return object_hit<false>(sc, id, r.o, r.d, record, u, v);   // spheres: cheaper to redo than to remember
+  else {
+    if (r.mb_id == id) { u = r.mb_u; v = r.mb_v; return r.mb_t; }
+    double t = object_hit<true>(sc, id, r.o, r.d, record, u, v);
+    r.mb_id = id; r.mb_t = t; r.mb_u = u; r.mb_v = v;
+    return t;
+  }
 }
 
 // confirm step by primitive id: the reference's arithmetic on the raw vertices (per-lane gather)
@@ -261,12 +290,12 @@ struct Deferred {
 // ANY = false: closest hit; confirmed hits go to r.best_t / r.best_id, r.bound prunes.
 // ANY = true : occlusion; `found` becomes true for a lane as soon as a confirmed hit satisfies occludes()
 //              (DEFER: as soon as a cull survivor MAY satisfy it; D.c1_id remembers which).
-template <bool ANY, bool DEFER, bool STATS>
+template <bool ANY, bool DEFER, bool STATS, bool PARAM>
 __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref, double fmargin,
-                                     WaveLds *lds, Stats &st, Deferred &D, bool &found)
+                                     WaveLds *lds, Stats &st, Deferred &D, bool &found, bool record)
 {
   // confirmed candidate (Scene.h:74-79): first candidate wins ties within eps
-  auto confirmed = [&](double t, int id, bool lane_on) {
+  auto confirmed = [&](double t, int id, bool lane_on, double hu = kInfty, double hv = kInfty) {
     if (!lane_on || !(t < kMiss)) return;
     if (ANY) {
       if (occludes(r.o, r.d, t, has_ref, ref)) found = true;
@@ -275,6 +304,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
       // the walk order here differs from the reference's, so the lower id is made to win explicitly
       if (r.best_id < 0 || t < r.best_t - kEps || (t <= r.best_t + kEps && id < r.best_id)) {
         r.best_t = t; r.best_id = id; r.bound = fmin(r.bound, t + r.tmargin);
+        if (PARAM) { r.best_u = hu; r.best_v = hv; }
       }
     }
   };
@@ -413,7 +443,9 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
             const bool lane_on = want && !(ANY && found);
             if (STATS && lane_on) st.exact_tests++;
             const double bt = r.best_t;
-            confirmed(lane_on ? leaf_other_t(sc, prim, r.o, r.d) : kMiss, prim, lane_on);
+            double hu = kInfty, hv = kInfty;
+            const double ht = lane_on ? leaf_other_hit<PARAM>(sc, r, prim, record, hu, hv) : kMiss;
+            confirmed(ht, prim, lane_on, hu, hv);
             if (!ANY && r.best_t != bt) lds->rays[lane].bound = r.bound;
           }
         } else {
@@ -477,7 +509,9 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           const int prim = uni(recs[i].prim_id);
           const bool lane_on = want && !(ANY && found);
           if (STATS && lane_on) st.exact_tests++;
-          confirmed(lane_on ? leaf_other_t(sc, prim, r.o, r.d) : kMiss, prim, lane_on);
+          double hu = kInfty, hv = kInfty;
+          const double ht = lane_on ? leaf_other_hit<PARAM>(sc, r, prim, record, hu, hv) : kMiss;
+          confirmed(ht, prim, lane_on, hu, hv);
         }
         }
         // the next chunk overwrites the LDS image: all reads above are complete (values consumed)
@@ -494,17 +528,18 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
 
 // Closest hit of one ray per lane (CScene::FirstInterPt_BSPTree, Scene.h:85-91; FirstInterPt, Scene.h:62-83,
 // when the scene has no tree).  Result in r.best_t / r.best_id.  All lanes of the wave call this together.
-template <bool STATS>
-__device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, bool active, WaveLds *lds, Stats &st)
+template <bool STATS, bool PARAM>
+__device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, bool active, WaveLds *lds, Stats &st, bool record = true)
 {
-  auto take = [&](double t, int id) {          // the update rule of Scene.h:74-79 (objects come in id order)
-    if (t < kMiss && (r.best_id < 0 || t < r.best_t - kEps)) { r.best_t = t; r.best_id = id; }
+  auto take = [&](double t, int id, double hu = kInfty, double hv = kInfty) {   // the update rule of Scene.h:74-79 (objects come in id order)
+    if (t < kMiss && (r.best_id < 0 || t < r.best_t - kEps)) { r.best_t = t; r.best_id = id; if (PARAM) { r.best_u = hu; r.best_v = hv; } }
   };
   if (!sc.has_tree) {
     for (int id = 0; id < sc.n_objects; id++) {
-      double t = active ? object_t(sc, id, r.o, r.d) : kMiss;
+      double hu, hv;
+      double t = active ? object_hit<PARAM>(sc, id, r.o, r.d, record, hu, hv) : kMiss;
       if (STATS && active) st.exact_tests++;
-      if (active) take(t, id);
+      if (active) take(t, id, hu, hv);
     }
     return;
   }
@@ -520,7 +555,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
   if (inf_id >= 0) r.bound = inf_t + r.tmargin;
   Deferred D; D.c1_t = D.c2_t = D.c3_t = kMiss; D.c1_id = D.c2_id = -1; D.redo = false;
   bool dummy = false;
-  walk<false, true, STATS>(sc, r, active, false, mk(0, 0, 0), 0.0, lds, st, D, dummy);
+  walk<false, true, STATS, PARAM>(sc, r, active, false, mk(0, 0, 0), 0.0, lds, st, D, dummy, record);
   // ---- confirm the survivors, all lanes together ----
   const bool h1 = active && D.c1_id >= 0, h2 = active && D.c2_id >= 0;
   double t1 = kMiss, t2 = kMiss;
@@ -539,24 +574,25 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
     if (STATS) { if (redo) st.pad++; if ((threadIdx.x & 63) == 0) st.pad += (1ull << 32); }
     RayState q = r;
     q.best_t = kMiss; q.best_id = -1; q.bound = (inf_id >= 0) ? inf_t + r.tmargin : kMiss;
-    walk<false, false, STATS>(sc, q, redo, false, mk(0, 0, 0), 0.0, lds, st, D, dummy);
-    if (redo) { r.best_t = q.best_t; r.best_id = q.best_id; }
+    walk<false, false, STATS, PARAM>(sc, q, redo, false, mk(0, 0, 0), 0.0, lds, st, D, dummy, record);
+    if (redo) { r.best_t = q.best_t; r.best_id = q.best_id; if (PARAM) { r.best_u = q.best_u; r.best_v = q.best_v; } }
   }
 #endif
   if (active && !redo) {
     // spheres etc. confirmed during the walk sit in r.best_*; merge the triangle survivors in object order
-    double e_t = r.best_t; int e_id = r.best_id;
+    double e_t = r.best_t; int e_id = r.best_id; const double e_u = r.best_u, e_v = r.best_v;
     r.best_t = kMiss; r.best_id = -1;
     const bool first1 = !(h2 && t2 < kMiss) || D.c1_id < D.c2_id;
     if (first1) { take(t1, D.c1_id); take(t2, D.c2_id); } else { take(t2, D.c2_id); take(t1, D.c1_id); }
-    take(e_t, e_id);
+    take(e_t, e_id, e_u, e_v);
   }
   if (active) take(inf_t, inf_id);
 }
 
 // Occlusion query of one ray per lane: is there a hit X with occludes() true (Scene.h:449, Light.h:66,91,147)?
-// t_limit: no hit beyond it can satisfy the predicate (kMiss if unbounded).
-template <bool STATS>
+// t_limit: no hit beyond it can satisfy the predicate (kMiss if unbounded).  Shadow tests go through
+// FirstInterPt_Unrecorded (Light.h:65, 90, 146; Scene.h:448 record = false).
+template <bool STATS, bool PARAM>
 __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref, double t_limit,
                                                WaveLds *lds, Stats &st)
 {
@@ -565,7 +601,8 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
     for (int id = 0; id < sc.n_objects; id++) {
       const bool lane_on = active && !found;
       if (__ballot(lane_on) == 0ull) break;
-      double t = lane_on ? object_t(sc, id, r.o, r.d) : kMiss;
+      double hu, hv;
+      double t = lane_on ? object_hit<PARAM>(sc, id, r.o, r.d, false, hu, hv) : kMiss;
       if (STATS && lane_on) st.exact_tests++;
       if (lane_on && t < kMiss && occludes(r.o, r.d, t, has_ref, ref)) found = true;
     }
@@ -582,7 +619,7 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
   const double fmargin = 3.0 * (len(ref - r.o) + 1.0) * r.tmargin;
   Deferred D; D.c1_t = D.c2_t = D.c3_t = kMiss; D.c1_id = D.c2_id = -1; D.redo = false;
   const bool pre = found;
-  walk<true, true, STATS>(sc, r, active && !pre, has_ref, ref, fmargin, lds, st, D, found);
+  walk<true, true, STATS, PARAM>(sc, r, active && !pre, has_ref, ref, fmargin, lds, st, D, found, false);
   // ---- confirm the survivor that stopped the walk ----
   const bool h1 = active && !pre && found && D.c1_id >= 0;
   bool ok = false;
@@ -595,7 +632,7 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
     if (STATS) { if (redo) st.pad++; if ((threadIdx.x & 63) == 0) st.pad += (1ull << 32); }
     bool f2 = false;
     RayState q = r; q.bound = t_limit;
-    walk<true, false, STATS>(sc, q, redo, has_ref, ref, fmargin, lds, st, D, f2);
+    walk<true, false, STATS, PARAM>(sc, q, redo, has_ref, ref, fmargin, lds, st, D, f2, false);
     if (redo) found = f2;
   }
 #endif
@@ -604,10 +641,18 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
 
 // ---- shading ------------------------------------------------------------------------------------
 // CBaseObject::Norm without bump map (Object.h:79-83) -> InitialNorm of the object type
-__device__ __forceinline__ V3 object_norm(const DevScene &sc, int id, V3 pt)
+// (u, v): surface parameters of the hit for Bezier / rotational objects.  The reference reads them from the object's
+// hidden cur_u / cur_v state, which a later intersection can overwrite before ReflectRay runs; here
+// the hit record carries them, so the normal always belongs to the hit being shaded.
+template <bool PARAM = false>
+__device__ __forceinline__ V3 object_norm(const DevScene &sc, int id, V3 pt, double hu = kInfty, double hv = kInfty)
 {
   const int type = sc.obj_type[id];
   const uint32_t k = sc.obj_index[id];
+  if constexpr (PARAM) {
+    if (type == 6) return bez_norm(sc.beziers[k], hu, hv);            // Object.h:1049
+    if (type == 5) return rot_norm(sc.rotationals[k], hu, hv);        // Object.h:799
+  }
   if (type == 1) {                                    // CTriangle::InitialNorm, Object.h:448-457
     const TriExact &T = sc.tri_exact[k];
     const TriShade &S = sc.tri_shade[k];
@@ -684,7 +729,7 @@ struct RngKey { uint64_t seed; uint32_t pixel, sample, path; };
 // Light.h:62-69 / 87-94, CAreaLight::luminosity (Light.h:126-162) and luminosity_BSPTree
 // (Scene.h:436-455).  Every shadow query is a wave-packet occlusion walk; point and parallel lights are
 // the one-sample case of the same loop.
-template <bool STATS>
+template <bool STATS, bool PARAM>
 __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLight &L, int li, V3 pt, bool active,
                                                    const RngKey &key, WaveLds *lds, Stats &st)
 {
@@ -709,7 +754,7 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
     // hits beyond the projection of the light position onto the ray can never satisfy the predicate
     const double t_limit = (type == 101) ? kMiss : fabs(dot(lp - pt, r.d)) + 1e-6 * (1.0 + sc.coord_scale);
     if (STATS && active) { st.rays++; st.shadow_rays++; }
-    bool occ = trace_occluded<STATS>(sc, r, active, type != 101, lp, t_limit, lds, st);
+    bool occ = trace_occluded<STATS, PARAM>(sc, r, active, type != 101, lp, t_limit, lds, st);
     if (!occ) lum += per;
   }
   return lum;
@@ -717,10 +762,12 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
 
 // CScene::LocalIllumination, Scene.h:93-122 (untextured: objColour = m_colour).  lum[li] = luminosity of
 // light li at pt, computed beforehand by the shadow pass (light_luminosity).
-__device__ __forceinline__ Col local_illumination(const DevScene &sc, V3 d, int id, V3 pt, const double *lum, V3 &N_out)
+template <bool PARAM = false>
+__device__ __forceinline__ Col local_illumination(const DevScene &sc, V3 d, int id, V3 pt, const double *lum, V3 &N_out,
+                                                  double hu = kInfty, double hv = kInfty)
 {
   Col colour = mkc(0, 0, 0);
-  V3 N = object_norm(sc, id, pt);
+  V3 N = object_norm<PARAM>(sc, id, pt, hu, hv);
   N_out = N;
   V3 norm = N;
   if (dot(d, norm) > kEps) norm = neg(norm);

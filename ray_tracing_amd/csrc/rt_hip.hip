@@ -110,6 +110,16 @@ struct Builder {
   std::string err;
   struct Sub { ChildRef ref; Box box; bool empty; };
 
+  static void rot_box(const rt_hip_rotational &z, double *mn, double *mx)
+  {
+    const int n = z.n_profile;
+    double r = 0;
+    for (int k = 0; k < n; k++) if (z.profile[k][0] > r) r = z.profile[k][0];
+    mn[0] = z.center[0] - r - kEps; mx[0] = z.center[0] + r + kEps;
+    mn[1] = z.center[1] - r - kEps; mx[1] = z.center[1] + r + kEps;
+    mn[2] = z.center[2] + std::min(z.profile[0][1], z.profile[n - 1][1]) - kEps;
+    mx[2] = z.center[2] + std::max(z.profile[0][1], z.profile[n - 1][1]) + kEps;
+  }
   // object AABBs as the reference builds them: CTriangle::InitializeAABB (Object.h:459-468),
   // CSphere ctor (Object.h:234); planes and circles keep the infinite default (Object.h:34)
   void object_boxes()
@@ -128,6 +138,17 @@ struct Builder {
       } else if (d->obj_type[i] == RT_HIP_SPHERE) {
         const rt_hip_sphere &s = d->spheres[k];
         for (int a = 0; a < 3; a++) { b.mn[a] = s.c[a] - s.r; b.mx[a] = s.c[a] + s.r; }
+        finite[i] = 1;
+      } else if (d->obj_type[i] == RT_HIP_BEZIER) {          // CBezierObject::InitializeAABB, Object.h:1204-1227
+        const rt_hip_bezier &z = d->beziers[k];
+        for (int a = 0; a < 3; a++) {
+          double lo = kInfty, hi = -kInfty;
+          for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) { lo = std::min(lo, z.ctrl[p][q][a]); hi = std::max(hi, z.ctrl[p][q][a]); }
+          b.mn[a] = lo + z.center[a]; b.mx[a] = hi + z.center[a];
+        }
+        finite[i] = 1;
+      } else if (d->obj_type[i] == RT_HIP_ROTATIONAL) {      // CRotationalObject::InitializeAABB, Object.h:954-970
+        rot_box(d->rotationals[k], b.mn, b.mx);
         finite[i] = 1;
       } else {
         for (int a = 0; a < 3; a++) { b.mn[a] = kInfty; b.mx[a] = kInfty; }
@@ -355,8 +376,8 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
 }
 
 // rt_hip_trace_closest: CScene::FirstInterPt_BSPTree / FirstInterPt for a list of rays
-template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_trace_closest(DevScene sc, const rt_hip_ray *rays, size_t n, rt_hip_hit *hits, Stats *gstats)
+template <bool STATS, bool PARAM>
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_trace_closest(DevScene sc, const rt_hip_ray *rays, size_t n, rt_hip_hit *hits, Stats *gstats, int record)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
@@ -367,17 +388,18 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_trace_closest(DevScen
   if (active) { const rt_hip_ray q = rays[i]; o = mk(q.o[0], q.o[1], q.o[2]); d = unitize(mk(q.d[0], q.d[1], q.d[2])); }
   RayState r; ray_setup(r, o, d, sc.coord_scale);
   if (STATS && active) st.rays++;
-  trace_closest<STATS>(sc, r, active, stack, st);
+  trace_closest<STATS, PARAM>(sc, r, active, stack, st, record != 0);
   if (active) {
     rt_hip_hit h; h.prim_id = r.best_id; h.reserved = 0; h.u = kInfty; h.v = kInfty;
     h.t = (r.best_id >= 0) ? r.best_t : kInfty;
+    if (PARAM && r.best_id >= 0) { h.u = r.best_u; h.v = r.best_v; }
     hits[i] = h;
   }
   if (STATS) stats_flush(gstats, st);
 }
 
-template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_trace_occluded(DevScene sc, const rt_hip_ray *rays, const double *ref_pts, size_t n,
+template <bool STATS, bool PARAM>
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_trace_occluded(DevScene sc, const rt_hip_ray *rays, const double *ref_pts, size_t n,
                                                               uint8_t *occluded, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
@@ -393,7 +415,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_trace_occluded(DevSce
   RayState r; ray_setup(r, o, d, sc.coord_scale);
   const double t_limit = ref_pts ? fabs(dot(ref - o, d)) + 1e-6 * (1.0 + sc.coord_scale) : kMiss;
   if (STATS && active) { st.rays++; st.shadow_rays++; }
-  bool occ = trace_occluded<STATS>(sc, r, active, ref_pts != nullptr, ref, t_limit, stack, st);
+  bool occ = trace_occluded<STATS, PARAM>(sc, r, active, ref_pts != nullptr, ref, t_limit, stack, st);
   if (active) occluded[i] = occ ? 1 : 0;
   if (STATS) stats_flush(gstats, st);
 }
@@ -481,8 +503,8 @@ __global__ void __launch_bounds__(1024) k_order(const unsigned char *flags, unsi
 }
 
 // level 0: camera / lens ray generation (Camera.h:65-67, 189-190) + closest hit, one 8x8 pixel tile per wave
-template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_primary(DevScene sc, RenderArgs A, PathNode *nodes, const unsigned int *order,
+template <bool STATS, bool PARAM>
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_primary(DevScene sc, RenderArgs A, PathNode *nodes, const unsigned int *order,
                                                                     unsigned char *shadow_flags, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
@@ -515,13 +537,14 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_primary(DevScene sc, 
   V3 d = unitize(unitize(cur - o));     // Camera.h:67 + CRay ctor (Geometry.h:253-254)
   RayState r; ray_setup(r, o, d, sc.coord_scale);
   if (STATS && active) st.rays++;
-  trace_closest<STATS>(sc, r, active, stack, st);
+  trace_closest<STATS, PARAM>(sc, r, active, stack, st);
   if (active) {
     PathNode &nd = nodes[(uint64_t)wave * 64 + lane];     // level 0 is stored in tile order (see node_of_pixel)
     nd.o[0] = o.x; nd.o[1] = o.y; nd.o[2] = o.z; nd.d[0] = d.x; nd.d[1] = d.y; nd.d[2] = d.z;
     nd.t = r.best_t; nd.weight = 1.0; nd.id = r.best_id;
     nd.pixel = (uint32_t)p; nd.sample = sample; nd.path = 1;
     nd.child_refr = -1; nd.child_refl = -1; nd.w_refr = 0; nd.w_refl = 0;
+    if (PARAM) { nd.col[0] = r.best_u; nd.col[1] = r.best_v; }      // (u, v) of the hit, until k_shade replaces them by the colour
   }
 #ifdef RT_STAMPS
   stamp(wave, 1, 1);
@@ -558,8 +581,8 @@ __device__ __forceinline__ uint64_t node_of_pixel(const RenderArgs &A, uint64_t 
 }
 
 // levels >= 1: closest hit for queued secondary rays
-template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n, Stats *gstats)
+template <bool STATS, bool PARAM>
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
@@ -570,15 +593,15 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_trace_nodes(DevScene 
   if (active) { o = mk(nodes[i].o[0], nodes[i].o[1], nodes[i].o[2]); d = mk(nodes[i].d[0], nodes[i].d[1], nodes[i].d[2]); }
   RayState r; ray_setup(r, o, d, sc.coord_scale);
   if (STATS && active) st.rays++;
-  trace_closest<STATS>(sc, r, active, stack, st);
-  if (active) { nodes[i].t = r.best_t; nodes[i].id = r.best_id; }
+  trace_closest<STATS, PARAM>(sc, r, active, stack, st);
+  if (active) { nodes[i].t = r.best_t; nodes[i].id = r.best_id; if (PARAM) { nodes[i].col[0] = r.best_u; nodes[i].col[1] = r.best_v; } }
   if (STATS) stats_flush(gstats, st);
 }
 
 // Shadow pass: luminosity of every light at every hit node (Scene.h:104-109), one wave-packet
 // occlusion walk per light sample.  Kept apart from k_shade so that the walk runs at full occupancy.
-template <bool STATS>
-__global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n, double *lum,
+template <bool STATS, bool PARAM>
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n, double *lum,
                                                       const unsigned int *order, RenderCounters *cnt, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
@@ -602,7 +625,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_shadow(DevScene sc, R
   unsigned long long my_shadow = 0;
   for (int li = 0; li < sc.n_lights; li++) {
     const DLight &L = sc.lights[li];
-    double l = light_luminosity<STATS>(sc, L, li, pt, hit, key, stack, st);
+    double l = light_luminosity<STATS, PARAM>(sc, L, li, pt, hit, key, stack, st);
     if (hit) { lum[(size_t)i * sc.n_lights + li] = l; my_shadow += (L.type == 102) ? (unsigned long long)L.sample_num * L.sample_num : 1ull; }
   }
   // ray census (always on: it is what rt_hip_last_ray_count reports)
@@ -618,6 +641,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MINWAVES) k_shadow(DevScene sc, R
 // the shadow pass and generation of the refracted / reflected child rays into the next level's queue.
 // direct_rgb != NULL (level 0 of a depth-1 frame, one sample per pixel): the colour is final, so it goes straight
 // to the frame (Camera.h:69) and the separate resolve pass over the level array is skipped.
+template <bool PARAM>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, PathNode *nodes, unsigned int n, int depth_left,
                                                      const double *lum, PathNode *next, unsigned int next_cap, RenderCounters *cnt,
                                                      double *direct_rgb, int32_t *direct_id)
@@ -635,7 +659,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, P
   int child_refr = -1, child_refl = -1; double w_refr = 0, w_refl = 0;
   bool want_refr = false, want_refl = false; V3 dir_refr = mk(0, 0, 0), dir_refl = mk(0, 0, 0);
   if (hit) {
-    c = local_illumination(sc, d, nd.id, pt, lum + (size_t)i * sc.n_lights, N);
+    c = local_illumination<PARAM>(sc, d, nd.id, pt, lum + (size_t)i * sc.n_lights, N, nd.col[0], nd.col[1]);   // col[0..1] = (u, v) until here
     if (depth_left > 1) {
       const DMaterial M = sc.materials[sc.obj_mat[nd.id]];
       double refrW = M.refrW, reflW = M.reflW;
@@ -813,6 +837,12 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   if ((d->n_triangles && !d->triangles) || (d->n_planes && !d->planes) || (d->n_spheres && !d->spheres) ||
       (d->n_circles && !d->circles) || (d->n_lights && !d->lights) || !d->materials || d->n_materials == 0)
     return fail(RT_HIP_EINVAL, "type arrays missing");
+  if ((d->n_beziers && !d->beziers) || (d->n_rotationals && !d->rotationals)) return fail(RT_HIP_EINVAL, "type arrays missing");
+  for (uint32_t k = 0; k < d->n_rotationals; k++) {
+    const rt_hip_rotational &z = d->rotationals[k];
+    if (z.n_profile < 2 || z.n_profile > 8) return fail(RT_HIP_EINVAL, "rotational object: 2..8 profile control points");
+    if (z.u_sample_num < 1 || z.u_sample_num > 4096) return fail(RT_HIP_EINVAL, "rotational object: u_sample_num out of range [1, 4096]");
+  }
   if (d->n_lights > 16) return fail(RT_HIP_EUNSUPPORTED, "more than 16 lights");
   for (uint32_t i = 0; i < d->n_objects; i++) {
     uint32_t k = d->obj_index[i], lim = 0;
@@ -821,6 +851,8 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
       case RT_HIP_INFTY_PLANE: lim = d->n_planes; break;
       case RT_HIP_SPHERE: lim = d->n_spheres; break;
       case RT_HIP_CIRCLE: lim = d->n_circles; break;
+      case RT_HIP_BEZIER: lim = d->n_beziers; break;
+      case RT_HIP_ROTATIONAL: lim = d->n_rotationals; break;
       default: return fail(RT_HIP_EUNSUPPORTED, "object type " + std::to_string((int)d->obj_type[i]) + " is not supported");
     }
     if (k >= lim) return fail(RT_HIP_EINVAL, "obj_index out of range at object " + std::to_string(i));
@@ -888,6 +920,15 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   for (uint32_t k = 0; k < d->n_planes; k++) { std::memcpy(planes[k].p0, d->planes[k].p0, 24); std::memcpy(planes[k].n, d->planes[k].n, 24); }
   for (uint32_t k = 0; k < d->n_spheres; k++) { std::memcpy(spheres[k].c, d->spheres[k].c, 24); spheres[k].r = d->spheres[k].r; }
   for (uint32_t k = 0; k < d->n_circles; k++) { std::memcpy(circles[k].p0, d->circles[k].p0, 24); std::memcpy(circles[k].n, d->circles[k].n, 24); circles[k].r = d->circles[k].r; }
+  std::vector<DBezier> beziers(d->n_beziers); std::vector<DRotational> rots(d->n_rotationals);
+  for (uint32_t k = 0; k < d->n_beziers; k++) { std::memcpy(beziers[k].c, d->beziers[k].ctrl, sizeof beziers[k].c); std::memcpy(beziers[k].center, d->beziers[k].center, 24); }
+  for (uint32_t k = 0; k < d->n_rotationals; k++) {
+    const rt_hip_rotational &z = d->rotationals[k]; DRotational &o = rots[k];
+    std::memset(&o, 0, sizeof o);
+    std::memcpy(o.prof, z.profile, sizeof o.prof); std::memcpy(o.center, z.center, 24);
+    o.u_range = z.u_range; o.n_prof = z.n_profile; o.u_sample_num = z.u_sample_num;
+    Builder::rot_box(z, o.bmin, o.bmax);
+  }
   std::vector<DMaterial> mats(d->n_materials);
   for (uint32_t k = 0; k < d->n_materials; k++) std::memcpy(&mats[k], &d->materials[k], sizeof(DMaterial));
   std::vector<DLight> lights(d->n_lights);
@@ -906,6 +947,8 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   up(upload(s, B.pairs, &D.pairs)); up(upload(s, B.stream, &D.leaf_stream));
   up(upload(s, root_objs, &D.root_objs)); up(upload(s, B.tri_exact, &D.tri_exact)); up(upload(s, tri_shade, &D.tri_shade));
   up(upload(s, planes, &D.planes)); up(upload(s, spheres, &D.spheres)); up(upload(s, circles, &D.circles));
+  up(upload(s, beziers, &D.beziers)); up(upload(s, rots, &D.rotationals));
+  D.has_param = (d->n_beziers || d->n_rotationals) ? 1 : 0;
   up(upload(s, types, &D.obj_type)); up(upload(s, index, &D.obj_index)); up(upload(s, omat, &D.obj_mat));
   up(upload(s, colour, &D.obj_colour)); up(upload(s, mats, &D.materials)); up(upload(s, lights, &D.lights));
   if (rc != RT_HIP_OK) { std::string m = g_err; rt_hip_scene_destroy(s); return fail(rc, m); }
@@ -981,6 +1024,15 @@ extern "C" int rt_hip_get_profile(rt_hip_scene *s, rt_hip_profile *out, int rese
   return RT_HIP_OK;
 }
 
+// launch the (STATS, PARAM) instantiation of a walk kernel
+#define RT_LAUNCH_SP(K, stats, param, grid, st, ...)                                                            \
+  do {                                                                                                          \
+    if (param) { if (stats) hipLaunchKernelGGL((K<true, true>), grid, dim3(RT_BLOCK), 0, st, __VA_ARGS__);      \
+                 else hipLaunchKernelGGL((K<false, true>), grid, dim3(RT_BLOCK), 0, st, __VA_ARGS__); }         \
+    else       { if (stats) hipLaunchKernelGGL((K<true, false>), grid, dim3(RT_BLOCK), 0, st, __VA_ARGS__);     \
+                 else hipLaunchKernelGGL((K<false, false>), grid, dim3(RT_BLOCK), 0, st, __VA_ARGS__); }        \
+  } while (0)
+
 static inline unsigned int blocks_for(size_t n) { return (unsigned int)((n + RT_BLOCK - 1) / RT_BLOCK); }
 
 extern "C" int rt_hip_trace_closest_dev(rt_hip_scene *s, const rt_hip_ray *d_rays, size_t n, int use_tree, int record,
@@ -994,8 +1046,8 @@ extern "C" int rt_hip_trace_closest_dev(rt_hip_scene *s, const rt_hip_ray *d_ray
   DevScene sc = s->dev; if (!use_tree) sc.has_tree = 0;
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(s, RT_HIP_K_TRACE_CLOSEST, st);
-  if (collect_stats) hipLaunchKernelGGL(k_trace_closest<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, sc, d_rays, n, d_hits, s->ctx->d_stats);
-  else hipLaunchKernelGGL(k_trace_closest<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, sc, d_rays, n, d_hits, (Stats *)nullptr);
+  RT_LAUNCH_SP(k_trace_closest, collect_stats != 0, sc.has_param != 0, dim3(blocks_for(n)), st, sc, d_rays, n, d_hits,
+               collect_stats ? s->ctx->d_stats : (Stats *)nullptr, record);
   HIP_TRY(hipGetLastError());
   return RT_HIP_OK;
 }
@@ -1026,8 +1078,8 @@ extern "C" int rt_hip_trace_occluded(rt_hip_scene *s, const rt_hip_ray *rays, co
   if (ref_pts) HIP_TRY(hipMemcpy(base + rb, ref_pts, pb, hipMemcpyHostToDevice));
   DevScene sc = s->dev; if (!use_tree) sc.has_tree = 0;
   { ProfScope ps(s, RT_HIP_K_TRACE_OCCLUDED, nullptr);
-  hipLaunchKernelGGL(k_trace_occluded<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, nullptr, sc, (const rt_hip_ray *)base,
-                     ref_pts ? (const double *)(base + rb) : (const double *)nullptr, n, (uint8_t *)(base + rb + pb), (Stats *)nullptr); }
+  RT_LAUNCH_SP(k_trace_occluded, false, sc.has_param != 0, dim3(blocks_for(n)), (hipStream_t) nullptr, sc, (const rt_hip_ray *)base,
+               ref_pts ? (const double *)(base + rb) : (const double *)nullptr, n, (uint8_t *)(base + rb + pb), (Stats *)nullptr); }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(occluded, base + rb + pb, n, hipMemcpyDeviceToHost));
   return RT_HIP_OK;
@@ -1070,6 +1122,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
   RenderCounters *cnt = (RenderCounters *)s->counter.p;
   Stats *gs = stats ? s->ctx->d_stats : nullptr;
+  const bool param = s->dev.has_param != 0;
   const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
   PathNode *L0 = (PathNode *)s->levels[0].p;
   // heavy-first order of the level-0 waves (only worth it with a tree)
@@ -1084,8 +1137,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   }
   {
     ProfScope ps(s, RT_HIP_K_PRIMARY, st);
-    if (stats) hipLaunchKernelGGL(k_primary<true>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, (const unsigned int *)order0, flags1, gs);
-    else hipLaunchKernelGGL(k_primary<false>, dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, (const unsigned int *)order0, flags1, gs);
+    RT_LAUNCH_SP(k_primary, stats, param, dim3(pblocks), st, s->dev, A, L0, (const unsigned int *)order0, flags1, gs);
   }
   if (s->dev.has_tree && s->dev.n_lights > 0) {
     ProfScope ps(s, RT_HIP_K_ORDER, st);
@@ -1113,22 +1165,22 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     PathNode *cur = (PathNode *)s->levels[lv].p;
     if (lv > 0) {
       ProfScope ps(s, RT_HIP_K_TRACE_NODES, st);
-      if (stats) hipLaunchKernelGGL(k_trace_nodes<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, cur, n, gs);
-      else hipLaunchKernelGGL(k_trace_nodes<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, cur, n, gs);
+      RT_LAUNCH_SP(k_trace_nodes, stats, param, dim3(blocks_for(n)), st, s->dev, cur, n, gs);
     }
     rc = s->lum.ensure((size_t)n * std::max(1, s->dev.n_lights) * sizeof(double)); if (rc) return rc;
     double *lum = (double *)s->lum.p;
     if (s->dev.n_lights > 0) {
       ProfScope ps(s, RT_HIP_K_SHADOW, st);
       const unsigned int *ord = (lv == 0) ? (const unsigned int *)order1 : nullptr;
-      if (stats) hipLaunchKernelGGL(k_shadow<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, (const PathNode *)cur, n, lum, ord, cnt, gs);
-      else hipLaunchKernelGGL(k_shadow<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, (const PathNode *)cur, n, lum, ord, cnt, gs);
+      RT_LAUNCH_SP(k_shadow, stats, param, dim3(blocks_for(n)), st, s->dev, A, (const PathNode *)cur, n, lum, ord, cnt, gs);
     }
     {
       ProfScope ps(s, RT_HIP_K_SHADE, st);
       const bool direct = direct_rgb && lv == 0 && depth == 1;
-      hipLaunchKernelGGL(k_shade, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt,
-                         direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr);
+      if (param) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt,
+                                    direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr);
+      else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt,
+                              direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr);
     }
     HIP_TRY(hipGetLastError());
     if (depth_left > 1) {

@@ -1,0 +1,222 @@
+// rt_param.hpp -- the two parametric primitives of the reference and their Newton intersections:
+// bicubic Bezier patch (CBezierSurface / CBezierObject, Bezier.h:91-138, Object.h:1085-1227) and Bezier
+// surface of revolution (CBezierCurve / CRotationalSurface / CRotationalObject, Bezier.h:8-87,
+// Object.h:791-1037).  Host + device.  The reference evaluates the surfaces by recursive de Casteljau; here
+// the same lerps run as loops in the same order (the recursion only repeats identical sub-results), so with
+// -ffp-contract=off the values round like the reference's.  Paths are relative to /root/reference/RayTracing/.
+#pragma once
+#include "rt_math.hpp"
+
+namespace rt {
+
+struct DBezier { double c[4][4][3]; double center[3]; };                     // controlPts[i][j], center
+struct DRotational {
+  double prof[8][2];            // profile control points (u = radius, v = height), CBezierCurve::controlPts
+  double center[3];
+  double u_range;               // uRange
+  int32_t n_prof, u_sample_num; // degree + 1, uSampleNum
+  double bmin[3], bmax[3];      // m_AABB (Object.h:954-970)
+};
+
+constexpr int kMaxStepNum = 10;          // Object.h:831
+constexpr double kMinStepLen = 1e-8;     // :832 (= eps)
+constexpr double kMaxDeviation = 0.3;    // :833
+constexpr double kPiRef = 3.1415926535;  // Geometry.h:13
+
+struct ParamHit { double t, u, v; };     // t = Dist(hit point, ray origin): what the scene compares (Scene.h:74); kMiss = none
+
+RT_HD V3 lerp3(V3 a, V3 b, double s) { return a * (1 - s) + b * s; }          // P*(1-s) + Q*s, Bezier.h:33,121-127
+RT_HD V3 cubic3(V3 p0, V3 p1, V3 p2, V3 p3, double s)
+{
+  V3 q0 = lerp3(p0, p1, s), q1 = lerp3(p1, p2, s), q2 = lerp3(p2, p3, s);
+  V3 r0 = lerp3(q0, q1, s), r1 = lerp3(q1, q2, s);
+  return lerp3(r0, r1, s);
+}
+RT_HD V3 bez_ctrl(const DBezier &B, int i, int j) { return mk(B.c[i][j][0], B.c[i][j][1], B.c[i][j][2]); }
+// Point3D(u,v,0,j,3,0): the cubic in u down column j (Bezier.h:120-121)
+RT_HD V3 bez_col(const DBezier &B, int j, double u) { return cubic3(bez_ctrl(B, 0, j), bez_ctrl(B, 1, j), bez_ctrl(B, 2, j), bez_ctrl(B, 3, j), u); }
+// Point3D(u,v,i,0,0,3): the cubic in v along row i (Bezier.h:124-125)
+RT_HD V3 bez_row(const DBezier &B, int i, double v) { return cubic3(bez_ctrl(B, i, 0), bez_ctrl(B, i, 1), bez_ctrl(B, i, 2), bez_ctrl(B, i, 3), v); }
+
+// S(u,v), dS/du, dS/dv (Bezier.h:98, 130-138).  S and dS/dv share the four column points.
+RT_HD void bez_eval(const DBezier &B, double u, double v, V3 &S, V3 &dSu, V3 &dSv)
+{
+  V3 c0 = bez_col(B, 0, u), c1 = bez_col(B, 1, u), c2 = bez_col(B, 2, u), c3 = bez_col(B, 3, u);
+  V3 a0 = lerp3(c0, c1, v), a1 = lerp3(c1, c2, v), a2 = lerp3(c2, c3, v);
+  V3 b0 = lerp3(a0, a1, v), b1 = lerp3(a1, a2, v);
+  S = lerp3(b0, b1, v);                       // Point3D(u,v,0,0,3,3)
+  dSv = (b1 - b0) * 3;                        // (Point3D(u,v,0,1,3,2) - Point3D(u,v,0,0,3,2)) * n
+  V3 r0 = bez_row(B, 0, v), r1 = bez_row(B, 1, v), r2 = bez_row(B, 2, v), r3 = bez_row(B, 3, v);
+  V3 e0 = lerp3(r0, r1, u), e1 = lerp3(r1, r2, u), e2 = lerp3(r2, r3, u);
+  dSu = (lerp3(e1, e2, u) - lerp3(e0, e1, u)) * 3;   // (Point3D(u,v,1,0,2,3) - Point3D(u,v,0,0,2,3)) * m
+}
+RT_HD V3 bez_point(const DBezier &B, double u, double v)
+{
+  V3 c0 = bez_col(B, 0, u), c1 = bez_col(B, 1, u), c2 = bez_col(B, 2, u), c3 = bez_col(B, 3, u);
+  return cubic3(c0, c1, c2, c3, v);
+}
+RT_HD V3 bez_norm(const DBezier &B, double u, double v)                        // Bezier.h:99
+{
+  V3 S, du, dv; bez_eval(B, u, v, S, du, dv);
+  return unitize(cross(du, dv));
+}
+
+// One Newton update shared by both objects (Object.h:857-862, 1109-1114)
+RT_HD void newton_step(V3 w, V3 o, V3 center, V3 S, V3 dPu, V3 dPv, double t, double u, double v, double &tp, double &up, double &vp)
+{
+  double D = dot(w, cross(dPu, dPv));
+  V3 df = center + S - (o + w * t);
+  tp = t + dot(dPu, cross(dPv, df)) / D;
+  up = u + dot(w, cross(dPv, df)) / D;
+  vp = v - dot(w, cross(dPu, df)) / D;
+}
+
+// CBezierObject::FirstInterPt and _Unrecorded (Object.h:1087-1202): 5x5 seeds, <= 10 Newton steps each
+RT_HD ParamHit bezier_hit(const DBezier &B, V3 o, V3 d)
+{
+  const V3 center = mk(B.center[0], B.center[1], B.center[2]);
+  double cur_u = kInfty, cur_v = kInfty, cur_t = kInfty;
+  bool have = false;
+  const double u_int = 1 / double(4), v_int = 1 / double(4);
+  for (int i = 0; i <= 4; i++) {
+    for (int j = 0; j <= 4; j++) {
+      double u = i * u_int, v = j * v_int;
+      double t = dist(bez_point(B, u, v) + center, o);
+      for (int step = 0; step < kMaxStepNum; step++) {
+        V3 S, dPu, dPv; bez_eval(B, u, v, S, dPu, dPv);
+        double tp, up, vp; newton_step(d, o, center, S, dPu, dPv, t, u, v, tp, up, vp);
+        if (up < -kMaxDeviation || up > 1 + kMaxDeviation || vp < -kMaxDeviation || vp > 1 + kMaxDeviation || tp < -kMaxDeviation) break;
+        if (len2(mk(tp - t, up - u, vp - v)) < kMinStepLen && tp > kEps && 0 < up && up < 1 && 0 < vp && vp < 1) {
+          have = true;
+          if (tp < cur_t - kEps) { cur_u = up; cur_v = vp; cur_t = tp; break; }
+        }
+        u = up; v = vp; t = tp;
+      }
+    }
+  }
+  ParamHit h; h.t = kMiss; h.u = kInfty; h.v = kInfty;
+  if (have) { h.t = dist(center + bez_point(B, cur_u, cur_v), o); h.u = cur_u; h.v = cur_v; }
+  return h;
+}
+
+// ---- CBezierCurve (Bezier.h:28-45) ----
+struct P2 { double u, v; };
+RT_HD P2 curve_pt(const DRotational &R, double t, int i, int deg)              // Point2D(t, i, deg)
+{
+  P2 q[8];
+  for (int k = 0; k <= deg; k++) { q[k].u = R.prof[i + k][0]; q[k].v = R.prof[i + k][1]; }
+  for (int lev = 1; lev <= deg; lev++)
+    for (int k = 0; k + lev <= deg; k++) { q[k].u = q[k].u * (1 - t) + q[k + 1].u * t; q[k].v = q[k].v * (1 - t) + q[k + 1].v * t; }
+  return q[0];
+}
+RT_HD P2 curve_tan(const DRotational &R, double t)                             // TanVec
+{
+  const int deg = R.n_prof - 1;
+  P2 a = curve_pt(R, t, 1, deg - 1), b = curve_pt(R, t, 0, deg - 1);
+  P2 r; r.u = (a.u - b.u) * deg; r.v = (a.v - b.v) * deg;
+  return r;
+}
+RT_HD P2 curve_norm(const DRotational &R, double t)                            // Norm; CPoint2D::Unitize, Geometry.h:219-225
+{
+  P2 tv = curve_tan(R, t);
+  P2 n; n.u = tv.v; n.v = -tv.u;
+  const bool zero = fabs(n.u) < kEps && fabs(n.v) < kEps, inf = fabs(n.u - kInfty) < kEps && fabs(n.v - kInfty) < kEps;
+  if (zero || inf) { n.u = kInfty; n.v = kInfty; return n; }
+  double l = sqrt(n.u * n.u + n.v * n.v);
+  P2 r; r.u = n.u / l; r.v = n.v / l;
+  return r;
+}
+// ---- CRotationalSurface (Bezier.h:65-87) ----
+RT_HD V3 rot_point(const DRotational &R, double t, double th) { P2 p = curve_pt(R, t, 0, R.n_prof - 1); return mk(p.u * cos(th), p.u * sin(th), p.v); }
+RT_HD V3 rot_norm(const DRotational &R, double t, double th) { P2 r = curve_norm(R, t); return unitize(mk(r.u * cos(th), r.u * sin(th), r.v)); }
+RT_HD V3 rot_ds_dt(const DRotational &R, double t, double th) { P2 dd = curve_tan(R, t); return mk(cos(th) * dd.u, sin(th) * dd.u, dd.v); }
+RT_HD V3 rot_ds_dth(const DRotational &R, double t, double th) { P2 p = curve_pt(R, t, 0, R.n_prof - 1); return mk(-(p.u) * sin(th), p.u * cos(th), 0); }
+
+// CBoundingBox::Collide == inftyPt2D (Geometry.h:302-342): the reference's own slab rule (a ray parallel to a slab is
+// never rejected by it; boxes behind the origin are accepted)
+RT_HD double ref_plane_t(double p0a, double oa, double da)                     // IntersectWithPlane for an axis normal
+{
+  if (fabs(da) < kEps) return kInfty;
+  double D = -p0a;
+  return -(D + oa) / da;
+}
+RT_HD bool ref_box_miss(const double *bmin, const double *bmax, V3 o, V3 d)
+{
+  const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  double tmin_a[3], tmax_a[3];
+  for (int a = 0; a < 3; a++) {
+    double t1 = ref_plane_t(bmin[a], oo[a], dd[a]), t2 = ref_plane_t(bmax[a], oo[a], dd[a]);
+    tmin_a[a] = dmin(t1, t2); tmax_a[a] = dmax(t1, t2);
+  }
+  double t_max = dmin(dmin(tmax_a[0], tmax_a[1]), tmax_a[2]);
+  for (int a = 0; a < 3; a++) tmin_a[a] = (tmin_a[a] == kInfty) ? -kInfty : tmin_a[a];
+  double t_min = dmax(dmax(tmin_a[0], tmin_a[1]), tmin_a[2]);
+  if (t_min < t_max + kEps) return fabs(t_min - kInfty) < kEps && fabs(t_max - kInfty) < kEps;   // == inftyPt2D is an eps compare
+  return true;
+}
+
+// CRotationalObject::t_v_Initial (Object.h:972-1037); false = inftyPt2D
+RT_HD bool rot_seed(const DRotational &R, double u, V3 o, V3 d, double &t_out, double &v_out)
+{
+  P2 pt2 = curve_pt(R, u, 0, R.n_prof - 1);
+  V3 p0 = mk(R.center[0], R.center[1], R.center[2] + pt2.v);
+  V3 n = mk(0, 0, 1);
+  V3 p; double t;
+  if (fabs(dot(n, d)) < 0.1) {
+    V3 l = p0 - o;
+    double tp = dot(l, d);
+    double d2 = len2(l) - tp * tp;
+    if (d2 > pt2.u * pt2.u + kEps) return false;
+    double t_prime = sqrt(pt2.u * pt2.u - d2);
+    if (len2(l) < pt2.u * pt2.u - kEps * 1000) { t = tp + t_prime; p = o + d * t; }
+    else if (len2(l) > pt2.u * pt2.u + kEps * 1000) {
+      t = tp - t_prime;
+      if (t > kEps) p = o + d * t; else return false;
+    } else {
+      if (tp < kEps * 1000) return false;
+      t = tp * 2; p = o + d * (tp * 2);
+    }
+  } else {
+    double D = -dot(p0, n);
+    t = -(D + dot(n, o)) / dot(n, d);
+    p = o + d * t;
+    if (t < kEps) return false;
+  }
+  // the seed must not compare equal to inftyPt2D (Object.h:848): only possible for |t|, |v| ~ 1e8
+  double cos_theta = (p - p0).x / len(p - p0);
+  double theta = acos(cos_theta);
+  double v = (p.y > p0.y || (p.y == p0.y && p.x > p0.x)) ? theta : 2 * kPiRef - theta;
+  if (fabs(t - kInfty) < kEps && fabs(v - kInfty) < kEps) return false;
+  t_out = t; v_out = v;
+  return true;
+}
+
+// CRotationalObject::FirstInterPt (record = true, t' > 10 eps) / _Unrecorded (t' > 5000 eps), Object.h:834-952
+RT_HD ParamHit rotational_hit(const DRotational &R, V3 o, V3 d, bool record)
+{
+  ParamHit h; h.t = kMiss; h.u = kInfty; h.v = kInfty;
+  if (ref_box_miss(R.bmin, R.bmax, o, d)) return h;
+  const V3 center = mk(R.center[0], R.center[1], R.center[2]);
+  double cur_u = kInfty, cur_v = kInfty, cur_t = kInfty;
+  bool have = false;
+  const double t_thr = record ? kEps * 10 : kEps * 5000;
+  const double u_int = R.u_range / double(R.u_sample_num);
+  for (int i = 0; i <= R.u_sample_num; i++) {
+    double u = i * u_int, v, t;
+    if (!rot_seed(R, u, o, d, t, v)) continue;
+    for (int step = 0; step < kMaxStepNum; step++) {
+      V3 dPu = rot_ds_dt(R, u, v), dPv = rot_ds_dth(R, u, v);
+      double tp, up, vp; newton_step(d, o, center, rot_point(R, u, v), dPu, dPv, t, u, v, tp, up, vp);
+      if (up < -kMaxDeviation || up > 1 + kMaxDeviation || tp < -kMaxDeviation) break;
+      if (len2(mk(tp - t, up - u, vp - v)) < kMinStepLen && tp > t_thr && 0 < up && up < R.u_range) {
+        have = true;
+        if (tp < cur_t) { cur_u = up; cur_v = vp; cur_t = tp; break; }
+      }
+      u = up; v = vp; t = tp;
+    }
+  }
+  if (have) { h.t = dist(center + rot_point(R, cur_u, cur_v), o); h.u = cur_u; h.v = cur_v; }
+  return h;
+}
+
+}  // namespace rt

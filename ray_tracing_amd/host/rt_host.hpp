@@ -148,6 +148,29 @@ class Scene {                    // CScene, Scene.h:12-60
     triangles_.push_back(t);
     return add(RT_HIP_TRIANGLE, (uint32_t)triangles_.size() - 1, m, col);
   }
+  // CBezierObject(controlPts[4][4], center, material, colour), Object.h:1075
+  int AddBezierObject(const Point3D ctrl[4][4], Point3D center, const Material &m, Colour col)
+  {
+    rt_hip_bezier b{};
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { b.ctrl[i][j][0] = ctrl[i][j].x; b.ctrl[i][j][1] = ctrl[i][j].y; b.ctrl[i][j][2] = ctrl[i][j].z; }
+    b.center[0] = center.x; b.center[1] = center.y; b.center[2] = center.z;
+    beziers_.push_back(b);
+    return add(RT_HIP_BEZIER, (uint32_t)beziers_.size() - 1, m, col);
+  }
+  // CRotationalObject(bezierCurve, center, material, colour, uSampleNum, uRange = 1), Object.h:818; profile = the
+  // curve's control points in AddControlPt order (Bezier.h:19), (u, v) = (radius, height)
+  int AddRotationalObject(const std::vector<std::array<double, 2>> &profile, Point3D center, const Material &m, Colour col,
+                          int uSampleNum, double uRange = 1)
+  {
+    if (profile.size() < 2 || profile.size() > 8) throw std::runtime_error("rotational object: 2..8 profile control points");
+    if (uSampleNum < 1) throw std::runtime_error("rotational object: uSampleNum < 1");
+    rt_hip_rotational r{};
+    for (size_t k = 0; k < profile.size(); k++) { r.profile[k][0] = profile[k][0]; r.profile[k][1] = profile[k][1]; }
+    r.center[0] = center.x; r.center[1] = center.y; r.center[2] = center.z;
+    r.u_range = uRange; r.n_profile = (int32_t)profile.size(); r.u_sample_num = uSampleNum;
+    rotationals_.push_back(r);
+    return add(RT_HIP_ROTATIONAL, (uint32_t)rotationals_.size() - 1, m, col);
+  }
   // Scene.h:150-166: every face -> CTriangle of its first three tuples, vertex = point*scale + center
   int ReadObjFile_Triangle(const std::string &filename, Point3D center, double scale, const Material &m, Colour col)
   {
@@ -216,6 +239,8 @@ class Scene {                    // CScene, Scene.h:12-60
     d.n_nodes = (uint32_t)nodes_.size(); d.nodes = nodes_.data();
     d.n_refs = (uint32_t)refs_.size(); d.refs = refs_.data();
     d.n_root_objects = (uint32_t)root_objects_.size(); d.root_objects = root_objects_.data();
+    d.n_beziers = (uint32_t)beziers_.size(); d.beziers = beziers_.data();
+    d.n_rotationals = (uint32_t)rotationals_.size(); d.rotationals = rotationals_.data();
     check(rt_hip_scene_create(ctx.get(), &d, leaf_refine_, &dev_), "rt_hip_scene_create");
     dev_ctx_ = ctx.get(); dirty_ = false;
     return dev_;
@@ -257,6 +282,22 @@ class Scene {                    // CScene, Scene.h:12-60
       } else if (type_[i] == RT_HIP_SPHERE) {                                             // Object.h:234
         const rt_hip_sphere &s = spheres_[index_[i]];
         for (int a = 0; a < 3; a++) { b.mn[a] = s.c[a] - s.r; b.mx[a] = s.c[a] + s.r; }
+      } else if (type_[i] == RT_HIP_BEZIER) {                                             // Object.h:1204-1227
+        const rt_hip_bezier &z = beziers_[index_[i]];
+        for (int a = 0; a < 3; a++) {
+          double lo = infty, hi = -infty;
+          for (int p = 0; p < 4; p++) for (int q = 0; q < 4; q++) { if (z.ctrl[p][q][a] < lo) lo = z.ctrl[p][q][a]; if (z.ctrl[p][q][a] > hi) hi = z.ctrl[p][q][a]; }
+          b.mn[a] = lo + z.center[a]; b.mx[a] = hi + z.center[a];
+        }
+      } else if (type_[i] == RT_HIP_ROTATIONAL) {                                         // Object.h:954-970
+        const rt_hip_rotational &z = rotationals_[index_[i]];
+        const int n = z.n_profile;
+        double r = 0;
+        for (int k = 0; k < n; k++) if (z.profile[k][0] > r) r = z.profile[k][0];
+        b.mn[0] = z.center[0] - r - eps; b.mx[0] = z.center[0] + r + eps;
+        b.mn[1] = z.center[1] - r - eps; b.mx[1] = z.center[1] + r + eps;
+        b.mn[2] = z.center[2] + std::min(z.profile[0][1], z.profile[n - 1][1]) - eps;
+        b.mx[2] = z.center[2] + std::max(z.profile[0][1], z.profile[n - 1][1]) + eps;
       }
       boxes_[i] = b;
     }
@@ -320,6 +361,7 @@ class Scene {                    // CScene, Scene.h:12-60
   std::vector<uint8_t> type_; std::vector<uint32_t> index_, mat_index_; std::vector<double> colour_;
   std::vector<rt_hip_triangle> triangles_; std::vector<rt_hip_plane> planes_; std::vector<rt_hip_sphere> spheres_;
   std::vector<rt_hip_circle> circles_; std::vector<rt_hip_material> materials_; std::vector<rt_hip_light> lights_;
+  std::vector<rt_hip_bezier> beziers_; std::vector<rt_hip_rotational> rotationals_;
   std::vector<Box> boxes_;
   std::vector<rt_hip_node> nodes_; std::vector<uint32_t> refs_, root_objects_;
   int max_obj_ = 100, max_depth_ = 40;

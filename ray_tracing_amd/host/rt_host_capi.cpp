@@ -32,6 +32,22 @@ int rth_add_plane(void *s, const double p0[3], const double n[3], const double m
 { return ((Scene *)s)->AddInftyPlane(Point3D(p0[0], p0[1], p0[2]), Point3D(n[0], n[1], n[2]), mat_from(m), Colour(col[0], col[1], col[2])); }
 int rth_add_circle(void *s, const double p0[3], const double n[3], double r, const double m[8], const double col[3])
 { return ((Scene *)s)->AddCircle(Point3D(p0[0], p0[1], p0[2]), Point3D(n[0], n[1], n[2]), r, mat_from(m), Colour(col[0], col[1], col[2])); }
+static void add_bezier_impl(Scene *s, const double *ctrl, const double *c, const double *m, const double *col)
+{
+  Point3D p[4][4];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) p[i][j] = Point3D(ctrl[(i * 4 + j) * 3], ctrl[(i * 4 + j) * 3 + 1], ctrl[(i * 4 + j) * 3 + 2]);
+  s->AddBezierObject(p, Point3D(c[0], c[1], c[2]), mat_from(m), Colour(col[0], col[1], col[2]));
+}
+static void add_rotational_impl(Scene *s, const double *prof, int n_prof, const double *c, int u_sample_num, double u_range, const double *m, const double *col)
+{
+  std::vector<std::array<double, 2>> pr;
+  for (int k = 0; k < n_prof; k++) pr.push_back(std::array<double, 2>{prof[2 * k], prof[2 * k + 1]});
+  s->AddRotationalObject(pr, Point3D(c[0], c[1], c[2]), mat_from(m), Colour(col[0], col[1], col[2]), u_sample_num, u_range);
+}
+int rth_add_bezier(void *s, const double ctrl[48], const double c[3], const double m[8], const double col[3])
+{ GUARD(add_bezier_impl((Scene *)s, ctrl, c, m, col)) }
+int rth_add_rotational(void *s, const double *prof, int n_prof, const double c[3], int u_sample_num, double u_range, const double m[8], const double col[3])
+{ GUARD(add_rotational_impl((Scene *)s, prof, n_prof, c, u_sample_num, u_range, m, col)) }
 int rth_add_triangle(void *s, const double v[9], const double *vn, const double m[8], const double col[3])
 {
   Point3D p[3], q[3];

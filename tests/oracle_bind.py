@@ -28,6 +28,8 @@ L.orc_add_sphere.argtypes = [_vp, d3, C.c_double, d8, d3]
 L.orc_add_plane.argtypes = [_vp, d3, d3, d8, d3]
 L.orc_add_circle.argtypes = [_vp, d3, d3, C.c_double, d8, d3]
 L.orc_add_triangle.argtypes = [_vp, _vp, _vp, d8, d3]
+L.orc_add_bezier.argtypes = [_vp, _vp, d3, d8, d3]
+L.orc_add_rotational.argtypes = [_vp, _vp, C.c_int, d3, C.c_int, C.c_double, d8, d3]
 L.orc_read_obj_triangle.argtypes = [_vp, C.c_char_p, d3, C.c_double, d8, d3]
 L.orc_num_objects.argtypes = [_vp]
 L.orc_get_triangle.argtypes = [_vp, C.c_int, _vp, _vp]
@@ -71,6 +73,14 @@ class OracleScene:
     def add_circle(self, p0, n, r, mat, colour):
         return L.orc_add_circle(self.h, d3(*p0), d3(*n), r, mat, d3(*colour))
 
+    def add_bezier(self, ctrl, center, mat, colour):
+        c = np.ascontiguousarray(ctrl, dtype=np.float64).reshape(48)
+        return L.orc_add_bezier(self.h, c.ctypes.data, d3(*center), mat, d3(*colour))
+
+    def add_rotational(self, profile, center, u_sample_num, u_range, mat, colour):
+        pr = np.ascontiguousarray(profile, dtype=np.float64).reshape(-1, 2)
+        return L.orc_add_rotational(self.h, pr.ctypes.data, pr.shape[0], d3(*center), int(u_sample_num), float(u_range), mat, d3(*colour))
+
     def add_triangle(self, v, vn, mat, colour):
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(9)
         vnp = None
@@ -113,13 +123,22 @@ class OracleScene:
         L.orc_tree_stats(self.h, st, box)
         return list(st), list(box)
 
-    def trace_closest(self, rays, use_bsp=True, record=True):
+    def trace_closest(self, rays, use_bsp=True, record=True, want_uv=False):
         r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         n = r.shape[0]
         ids = np.zeros(n, np.int32)
         pts = np.zeros((n, 3))
-        L.orc_trace_closest(self.h, r.ctypes.data, n, int(use_bsp), int(record), ids.ctypes.data, pts.ctypes.data, None)
-        return ids, pts
+        uv = np.zeros((n, 2))
+        L.orc_trace_closest(self.h, r.ctypes.data, n, int(use_bsp), int(record), ids.ctypes.data, pts.ctypes.data,
+                            uv.ctypes.data if want_uv else None)
+        return (ids, pts, uv) if want_uv else (ids, pts)
+
+    def object_first_inter_pt(self, obj_id, ray):
+        """CBaseObject::FirstInterPt of one object: (point, (u, v)); point = (1e8,)*3 for a miss"""
+        r = np.ascontiguousarray(ray, dtype=np.float64).reshape(6)
+        pt = np.zeros(3); uv = np.zeros(2)
+        L.orc_object_first_inter_pt(self.h, int(obj_id), r.ctypes.data, pt.ctypes.data, uv.ctypes.data)
+        return pt, uv
 
     def render_whitted(self, cam, background=(0, 0, 0), seed=0, first=0, count=0, threads=0, counters=False):
         w, h = C.c_int(), C.c_int()

@@ -134,3 +134,62 @@ def fnv_hash_ids(ids):
         h ^= (i + 1) & 0xFFFFFFFF
         h = (h * 1099511628211) & M
     return "%016x" % h
+
+
+# ---- parametric objects (SURVEY 8d C4 / C5 geometry, untextured) ---------------------------------------------
+PAPER_CTRL = [[(-2, 6, 9), (-1, 2, 9), (-1, -2, 9), (-2, -6, 9)],
+              [(-1, 6, 3), (0, 2, 3), (0, -2, 3), (-1, -6, 3)],
+              [(-1, 6, -3), (0, 2, -2), (0, -2, -3), (-1, -6, -3)],
+              [(-2, 6, -9), (-1, 2, -9), (-1, -2, -9), (-2, -6, -9)]]      # Layout.h:113-117
+PAPER_CENTER = (20, 25, 17)                                               # Layout.h:118
+
+C4_CAMERA = dict(view=(-10, 20, 20), eye=(1, 0, 0), left=(-0.8, -1, 0), dist=5, hor=6, ver=3.375, res=320, depth=2)
+
+
+def build_paper(gpu=True, oracle=True, bsp=True, mesh=True, material="rubber"):
+    """C4: Layout2_WallAndPaper (Layout.h:104-133) untextured: wall plane, the bicubic "paper" patch and a
+    triangle mesh beside it (the icosahedron asset stands in for WallLight.obj), parallel light (1,-1,-1) L=2."""
+    P = _Pair(0.05, gpu, oracle)
+    P.call("add_plane", (20, 0, 0), (-1, 0, 0), mat=P.mat("rubber"), colour=(120, 120, 120))
+    P.call("add_bezier", PAPER_CTRL, PAPER_CENTER, mat=P.mat(material), colour=(255, 255, 255))
+    if mesh:
+        P.call("read_obj_triangle", ICOSA_OBJ, (18.5, 13, 20), 0.004, mat=P.mat("metal"), colour=(50, 50, 60))
+    P.call("add_parallel_light", (1, -1, -1), 2.0)
+    if bsp:
+        P.call("construct_bsp")
+    return P.g, P.o
+
+
+CUP2_PROFILES = [([(2, 0.2), (0.2, 0.2), (0.2, 2.2), (0.2, 4.2)], 50),          # Object_Cup2, Layout.h:190-235
+                 ([(0.2, 4.2), (0.2, 6.2), (2, 6.2), (1.7, 10.2)], 50),
+                 ([(1.6, 10.2), (1.65, 8.2), (1.3, 6.2), (0, 6.2)], 50),
+                 ([(2, 0), (2.1, 0.1), (2, 0.2)], 10),
+                 ([(1.7, 10.2), (1.65, 10.3), (1.6, 10.2)], 10)]
+
+C5_CAMERA = dict(view=(-23.5, 27.5, 24), eye=(2.9, -3, -2), left=(-1, -1, 0), dist=15, hor=8, ver=4.5, res=240, depth=8)
+
+
+def build_wine(gpu=True, oracle=True, cups=((-2, -2, 0),), light="point", cup_material="glass", u_samples=None):
+    """C5 geometry: Layout5_Wine (Layout.h:237-300) untextured and WITHOUT a tree: three planes, per cup the
+    five surfaces of revolution of Object_Cup2, the wine surface (uRange 0.7) and its circle lid."""
+    e = 1e-8
+    P = _Pair(0.5, gpu, oracle)
+    P.call("add_plane", (0, 0, 0), (0, 0, 1), mat=P.mat("rubber"), colour=(140, 100, 60))
+    P.call("add_plane", (10, 0, 0), (-1, 0, 0), mat=P.mat("plastic"), colour=(90, 90, 110))
+    P.call("add_plane", (0, -10, 0), (0, 1, 0), mat=P.mat("plastic"), colour=(90, 110, 90))
+    wine = [(0, 6.2 - 10 * e), (1.3 + 10 * e, 6.2 - 10 * e), (1.65 + 10 * e, 8.2 - 10 * e), (1.6 + 10 * e, 10.2 - 10 * e)]
+    for c in cups:
+        for prof, ns in CUP2_PROFILES:
+            P.call("add_rotational", prof, c, (u_samples or ns), 1.0, mat=P.mat(cup_material), colour=(155, 155, 155))
+        P.call("add_rotational", wine, c, (u_samples or 50), 0.7, mat=P.mat("ice"), colour=(151, 57, 29))
+        # CCircle at the curve point of u = 0.7 (Layout.h:262-264), de Casteljau on the host
+        pts = np.array(wine, dtype=np.float64)
+        t = 0.7
+        while len(pts) > 1:
+            pts = pts[:-1] * (1 - t) + pts[1:] * t
+        P.call("add_circle", (c[0], c[1], float(pts[0][1])), (0, 0, 1), float(pts[0][0]) + 10 * e, mat=P.mat("ice"), colour=(151, 57, 29))
+    if light == "point":
+        P.call("add_point_light", (-10, 25, 25), 2.0)
+    elif light == "area":
+        P.call("add_area_light", (-10, 25, 25), 2.0, 2.0, 2)
+    return P.g, P.o
