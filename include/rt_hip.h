@@ -211,6 +211,25 @@ int rt_hip_render_focusing(rt_hip_scene *scene, const rt_hip_camera *cam, const 
 int rt_hip_render_focusing_dev(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
                                double *d_rgb, void *stream);
 
+/* ---- progressive photon mapping: CPhotonMapper (PhotonMapper.h:133-376) driven as in CCamera::Render_PhotonMapper
+ * (Camera.h:291-313).  begin = the eye pass (RayTracingPass per pixel, :159-220: Whitted + a hit point on every
+ * diffuse surface of the ray tree); photon_num = photonNum (:155, 0 -> 50000), times = the passes that will be run
+ * (N_emitted, :225).  pass = one iteration of PhotonMappingPass (:226-238).  For several GPUs: every rank calls
+ * begin (same hit points), traces its own photon range, all-reduces the accumulators (sum), and calls update.
+ * resolve = the CV_8UC3 picture as R,G,B doubles 0..255. ---- */
+typedef struct rt_hip_ppm rt_hip_ppm;
+int rt_hip_ppm_begin(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params, uint32_t photon_num, uint32_t times,
+                     rt_hip_ppm **out);
+int rt_hip_ppm_info(rt_hip_ppm *ppm, uint64_t *n_hitpoints, uint64_t *photons_per_pass, uint64_t *photon_segments, uint64_t *photon_hits);
+int rt_hip_ppm_trace(rt_hip_ppm *ppm, uint32_t pass_index, uint64_t photon_first, uint64_t photon_count, void *stream);
+int rt_hip_ppm_accumulators(rt_hip_ppm *ppm, double **d_acc, uint64_t *n_doubles);   /* 4 per hit point: M, tau R, G, B */
+int rt_hip_ppm_update(rt_hip_ppm *ppm, void *stream);                                  /* RadianceEvaluation, :357-376 */
+int rt_hip_ppm_pass(rt_hip_ppm *ppm, uint32_t pass_index);                             /* trace(all) + update, synchronous */
+int rt_hip_ppm_resolve(rt_hip_ppm *ppm, double *rgb);
+int rt_hip_ppm_resolve_dev(rt_hip_ppm *ppm, double *d_rgb, void *stream);
+int rt_hip_ppm_hitpoints(rt_hip_ppm *ppm, double *out /* 11 doubles each: pixel, path, pt[3], norm[3], wgt, R, N */);
+int rt_hip_ppm_end(rt_hip_ppm *ppm);
+
 /* Per-kernel device time, measured with hipEvents recorded on the caller's stream around every
  * kernel launch of this scene while profiling is on (rt_hip_set_profiling).  Index = RT_HIP_K_*. */
 #define RT_HIP_K_PRIMARY        0   /* camera/lens ray generation + closest hit (level 0) */

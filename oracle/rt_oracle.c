@@ -968,6 +968,11 @@ static col_t local_illumination(orc_scene *s, ray_t ray, inter_t in, const rng_c
   return colour;
 }
 
+/* CHitpoint, PhotonMapper.h:14-26 (+ the position in the ray tree, used as a key by the tests) */
+typedef struct { v3 pt, norm, omega; int h, v; double wgt, R, N, M; col_t tau; uint32_t pixel, path; } hitpoint_t;
+typedef struct { hitpoint_t *a; size_t n, cap; int W; } hp_sink_t;
+static _Thread_local hp_sink_t *tl_hp = NULL;      /* non-NULL: ray_tracer is CPhotonMapper::RayTracingPass (PhotonMapper.h:159-220) */
+
 static const double THRESHOLD = 0.1;                                      /* RayTracer.h:7 */
 static col_t ray_tracer(orc_scene *s, ray_t ray, int depth, double weight, col_t bg, rng_ctx g,
                         int32_t *first_id)
@@ -979,6 +984,19 @@ static col_t ray_tracer(orc_scene *s, ray_t ray, int depth, double weight, col_t
   if (in.obj < 0) return bg;
   const obj_t *o = &s->objs[in.obj];
   colour = local_illumination(s, ray, in, &g);
+  if (tl_hp && o->mat.reflW == 0 && o->mat.refrW == 0) {                  /* PhotonMapper.h:174-186 */
+    hp_sink_t *k = tl_hp;
+    if (k->n == k->cap) { k->cap = k->cap ? k->cap * 2 : 1024; k->a = (hitpoint_t *)realloc(k->a, k->cap * sizeof(hitpoint_t)); }
+    hitpoint_t *hp = &k->a[k->n++];
+    memset(hp, 0, sizeof *hp);
+    hp->pt = in.pt;
+    hp->norm = obj_norm(o, in.pt, in.u, in.v);
+    if (v_dot(ray.d, hp->norm) > EPS) hp->norm = v_neg(hp->norm);
+    hp->omega = ray.d;
+    hp->h = (int)(g.pixel % (uint32_t)k->W); hp->v = (int)(g.pixel / (uint32_t)k->W);
+    hp->wgt = weight; hp->R = 1; hp->N = 0; hp->M = 0; hp->tau = C3(0, 0, 0);      /* R_initial, :10, :25 */
+    hp->pixel = g.pixel; hp->path = g.path;
+  }
   if (depth > 1) {
     int total_reflect = 0;
     double refrW = obj_refrW(o, ray, in.pt, in.u, in.v);
@@ -1139,6 +1157,227 @@ void orc_render_focusing(orc_scene *s, const orc_camera *c, double radius, int s
 }
 
 /* ------------------------------------------------------------------ batch queries for tests */
+
+/* ------------------------------------------------------------------ progressive photon mapping (PhotonMapper.h, Camera.h:291-313) */
+static const double R_INITIAL = 1, PPM_ALPHA = 0.8;                       /* PhotonMapper.h:10-11 */
+typedef struct kd_node { hitpoint_t hp; int split_axis; struct kd_node *l, *r; } kd_node;
+typedef struct { v3 pt, norm; col_t colour; } photon_hp_t;                /* CPhotonHP, :34-40 */
+struct orc_ppm {
+  orc_scene *s; cam_t cam; uint64_t seed; int photon_num, times; long long n_emitted;
+  hitpoint_t *hps; size_t n_hp;
+  kd_node *root;
+  unsigned char *picture;                                                 /* CV_8UC3, stored R,G,B here */
+  int64_t photon_segments, photon_hits;
+};
+
+static int cmp_axis;
+static int cmp_hp(const void *a, const void *b)
+{
+  const hitpoint_t *x = (const hitpoint_t *)a, *y = (const hitpoint_t *)b;
+  double p = cmp_axis == 0 ? x->pt.x : (cmp_axis == 1 ? x->pt.y : x->pt.z), q = cmp_axis == 0 ? y->pt.x : (cmp_axis == 1 ? y->pt.y : y->pt.z);
+  return (p < q) ? -1 : (p > q ? 1 : 0);
+}
+/* KdTree::BuildTree, PhotonMapper.h:76-129 (max-variance axis, median; std::sort there, qsort here: ties may order
+ * differently, which changes the shape of the tree but not what a range query returns) */
+static kd_node *kd_build(hitpoint_t *h, size_t n)
+{
+  if (n == 0) return NULL;
+  kd_node *node = (kd_node *)calloc(1, sizeof *node);
+  if (n == 1) { node->hp = h[0]; node->split_axis = 0; return node; }
+  double mx = 0, my = 0, mz = 0, vx = 0, vy = 0, vz = 0;
+  for (size_t i = 0; i < n; i++) { mx += h[i].pt.x; my += h[i].pt.y; mz += h[i].pt.z; }
+  mx /= (double)n; my /= (double)n; mz /= (double)n;
+  for (size_t i = 0; i < n; i++) {
+    vx += (h[i].pt.x - mx) * (h[i].pt.x - mx); vy += (h[i].pt.y - my) * (h[i].pt.y - my); vz += (h[i].pt.z - mz) * (h[i].pt.z - mz);
+  }
+  if (vx >= vy && vx >= vz) node->split_axis = 0; else if (vy >= vx && vy >= vz) node->split_axis = 1; else node->split_axis = 2;
+  cmp_axis = node->split_axis;
+  qsort(h, n, sizeof *h, cmp_hp);
+  node->hp = h[n / 2];
+  node->l = kd_build(h, n / 2);
+  if (n >= 3) node->r = kd_build(h + n / 2 + 1, n - n / 2 - 1);
+  return node;
+}
+static void kd_free(kd_node *n) { if (!n) return; kd_free(n->l); kd_free(n->r); free(n); }
+
+/* random(r, x) for photons: draw number `d` of photon `photon` in pass `pass` */
+typedef struct { uint64_t seed; uint32_t pass, photon, draw; } prng_t;
+static inline double photon_random(double r, int x, prng_t *g)
+{
+  uint32_t k = orc_rng_u32(g->seed ^ 0x50484F544F4E53ULL, g->pass, g->photon, g->draw++) >> 1;
+  return 2 * r * (double)(k % (uint32_t)x) / (double)x - r;
+}
+/* CPhotonMapper::RandomDirection, :146; draws in x, y, z order (pinned) */
+static v3 random_direction(prng_t *g)
+{
+  double x = photon_random(1000, 1000, g), y = photon_random(1000, 1000, g), z = photon_random(1000, 1000, g);
+  return v_unitize(V3(x, y, z));
+}
+
+/* CPhotonMapper::AccumulatePhotons, :334-355 */
+static void kd_accumulate(orc_ppm *m, kd_node *node, const photon_hp_t *ph)
+{
+  if (!node) return;
+  if (v_dist(node->hp.pt, ph->pt) < node->hp.R + EPS && v_dot(node->hp.norm, ph->norm) > EPS * 100) {
+    node->hp.M++;
+    node->hp.tau = c_add(node->hp.tau, c_div(ph->colour, (PI_REF * node->hp.R * node->hp.R * (double)m->n_emitted) / 3000));
+  }
+  v3 normal = V3(0, 0, 0);
+  if (node->split_axis == 0) normal.x = 1;
+  if (node->split_axis == 1) normal.y = 1;
+  if (node->split_axis == 2) normal.z = 1;
+  double l = v_dot(v_sub(ph->pt, node->hp.pt), normal);
+  if (l < EPS || fabs(l) < R_INITIAL + EPS) kd_accumulate(m, node->l, ph);
+  if (l > -EPS || fabs(l) < R_INITIAL + EPS) kd_accumulate(m, node->r, ph);
+}
+static inline unsigned char sat_u8(double x)       /* cv::saturate_cast<uchar>(double): round to nearest even, clamp */
+{ double r = nearbyint(x); return (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r)); }
+/* CPhotonMapper::RadianceEvaluation, :357-376, CV_8UC3 picture */
+static void kd_radiance(orc_ppm *m, kd_node *node)
+{
+  if (!node) return;
+  hitpoint_t *hp = &node->hp;
+  unsigned char *px = &m->picture[3 * ((size_t)hp->v * m->cam.W + hp->h)];
+  const double t[3] = {hp->tau.r, hp->tau.g, hp->tau.b};
+  for (int c = 0; c < 3; c++) {
+    unsigned char tb = (unsigned char)t[c];                               /* Vec3b(tau...): double -> uchar truncation */
+    unsigned char add = sat_u8((double)tb * hp->wgt);                     /* Vec3b * double */
+    int sum = (int)px[c] + (int)add;                                      /* Vec3b += : saturating */
+    px[c] = (unsigned char)(sum > 255 ? 255 : sum);
+  }
+  hp->tau = C3(0, 0, 0);
+  if (hp->M > 0) hp->R *= sqrt((hp->N + hp->M * PPM_ALPHA) / (hp->N + hp->M));
+  hp->N += hp->M * PPM_ALPHA;
+  hp->M = 0;
+  kd_radiance(m, node->l); kd_radiance(m, node->r);
+}
+
+static int cmp_key(const void *a, const void *b)
+{
+  const hitpoint_t *x = (const hitpoint_t *)a, *y = (const hitpoint_t *)b;
+  if (x->pixel != y->pixel) return x->pixel < y->pixel ? -1 : 1;
+  return x->path < y->path ? -1 : (x->path > y->path ? 1 : 0);
+}
+
+/* Camera.h:291-308: eye pass (RayTracingPass per pixel) + ConstructKdTree */
+orc_ppm *orc_ppm_begin(orc_scene *s, const orc_camera *c, const double bg[3], uint64_t seed, int photon_num, int times)
+{
+  orc_ppm *m = (orc_ppm *)calloc(1, sizeof *m);
+  m->s = s; m->cam = cam_init(c); m->seed = seed; m->photon_num = photon_num > 0 ? photon_num : 50000; m->times = times;
+  m->n_emitted = (long long)times * s->n_lights * m->photon_num;          /* :225 */
+  const cam_t k = m->cam;
+  const size_t total = (size_t)k.W * k.H;
+  m->picture = (unsigned char *)calloc(total, 3);
+  col_t bgc = C3(bg[0], bg[1], bg[2]);
+  hp_sink_t all = {NULL, 0, 0, k.W};
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    hp_sink_t mine = {NULL, 0, 0, k.W};
+    tl_hp = &mine;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 64)
+#endif
+    for (long long p = 0; p < (long long)total; p++) {
+      int v = (int)(p / k.W), h = (int)(p % k.W);
+      v3 cur = cam_cur_pt(&k, h, v);
+      ray_t ray = mk_ray(k.view_pt, v_unitize(v_sub(cur, k.view_pt)));
+      rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = 0; g.path = 1;
+      col_t col = ray_tracer(s, ray, k.depth, 1, bgc, g, NULL);
+      m->picture[3 * p] = (unsigned char)col.r; m->picture[3 * p + 1] = (unsigned char)col.g; m->picture[3 * p + 2] = (unsigned char)col.b;   /* :306 */
+    }
+    tl_hp = NULL;
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+    {
+      all.a = (hitpoint_t *)realloc(all.a, (all.n + mine.n + 1) * sizeof(hitpoint_t));
+      memcpy(all.a + all.n, mine.a, mine.n * sizeof(hitpoint_t)); all.n += mine.n;
+    }
+    free(mine.a);
+  }
+  qsort(all.a, all.n, sizeof(hitpoint_t), cmp_key);     /* a fixed order for the tests; the kd build re-sorts anyway */
+  m->hps = all.a; m->n_hp = all.n;
+  hitpoint_t *tmp = (hitpoint_t *)malloc((all.n + 1) * sizeof(hitpoint_t));
+  memcpy(tmp, all.a, all.n * sizeof(hitpoint_t));
+  m->root = kd_build(tmp, all.n);                        /* ConstructKdTree, :141 */
+  free(tmp);
+  return m;
+}
+
+/* one iteration of the loop of PhotonMappingPass (:226-238): GeneratePhotons, TracePhotons, AccumulatePhotons, RadianceEvaluation */
+void orc_ppm_pass(orc_ppm *m, int pass_index)
+{
+  orc_scene *s = m->s;
+  uint32_t photon = 0;
+  for (int li = 0; li < s->n_lights; li++) {
+    const light_t *L = &s->lights[li];
+    if (L->type != ORC_POINT_LIGHT && L->type != ORC_AREA_LIGHT) continue;                 /* :245, :251 */
+    const int sn = (L->type == ORC_AREA_LIGHT) ? L->sample_num : 1;
+    for (int t = 0; t < m->photon_num; t++) for (int i = 0; i < sn; i++) for (int j = 0; j < sn; j++, photon++) {
+      prng_t g = {m->seed, (uint32_t)pass_index, photon, 0};
+      v3 origin; col_t colour;
+      if (L->type == ORC_POINT_LIGHT) { origin = L->pos_or_dir; colour = c_mul(C3(255, 255, 255), L->lum); }           /* :249 */
+      else {
+        double r = (L->len / (double)L->sample_num) / 2;                                                               /* :256-265 */
+        v3 O = V3(L->pos_or_dir.x - L->sample_num * r, L->pos_or_dir.y - L->sample_num * r, L->pos_or_dir.z);
+        double x0 = O.x + i * r * 2, y0 = O.y + j * r * 2, z0 = O.z;
+        double rx = photon_random(r, 1000, &g), ry = photon_random(r, 1000, &g);
+        origin = V3(x0 + rx, y0 + ry, z0); colour = c_mul(C3(255, 255, 255), L->lum_per_sample);
+      }
+      ray_t path = mk_ray(origin, random_direction(&g));
+      double weight = 1;
+      /* TracePhotons, :273-332 */
+      inter_t in = first_inter_pt_bsp(s, path, 1); m->photon_segments++;
+      for (int b = 0; b < 10 && weight > 0.2 && in.obj >= 0; b++) {
+        const obj_t *o = &s->objs[in.obj];
+        v3 hp = in.pt;
+        v3 norm = obj_norm(o, hp, in.u, in.v);
+        if (o->mat.reflW == 0 && o->mat.refrW == 0) {
+          if (v_dot(path.d, norm) > EPS) norm = v_neg(norm);
+          photon_hp_t ph; ph.pt = hp; ph.norm = norm; ph.colour = c_mul(colour, weight);
+          kd_accumulate(m, m->root, &ph); m->photon_hits++;               /* the photonHps stack only defers this (:231-236) */
+          v3 dir = random_direction(&g);
+          if (v_dot(dir, norm) < 0) dir = v_neg(dir);
+          path = mk_ray(hp, dir);
+          weight /= 4;
+        } else if (o->mat.refrW > 0) {
+          ray_t np = obj_refract_ray(o, path, hp, in.u, in.v);
+          if (!is_infty_pt(np.d)) path = np; else path = obj_reflect_ray(o, path, hp, in.u, in.v);
+        } else if (o->mat.reflW > 0) {
+          path = obj_reflect_ray(o, path, hp, in.u, in.v);
+        }
+        col_t oc = o->colour;                                             /* CBaseObject::colour, untextured */
+        double sc = (colour.r + colour.g + colour.b) / (oc.r + oc.g + oc.b);
+        colour = c_div(c_add(colour, c_mul(oc, sc)), 2);
+        in = first_inter_pt_bsp(s, path, 1); m->photon_segments++;
+      }
+    }
+  }
+  kd_radiance(m, m->root);
+}
+
+size_t orc_ppm_num_hitpoints(const orc_ppm *m) { return m->n_hp; }
+static void kd_collect(const kd_node *n, hitpoint_t *out, size_t *k) { if (!n) return; out[(*k)++] = n->hp; kd_collect(n->l, out, k); kd_collect(n->r, out, k); }
+/* hit points sorted by (pixel, path): 14 doubles each = pixel, path, pt(3), norm(3), wgt, R, N, tau(3) */
+void orc_ppm_hitpoints(const orc_ppm *m, double *out)
+{
+  hitpoint_t *tmp = (hitpoint_t *)malloc((m->n_hp + 1) * sizeof(hitpoint_t));
+  size_t k = 0; kd_collect(m->root, tmp, &k);
+  qsort(tmp, k, sizeof(hitpoint_t), cmp_key);
+  for (size_t i = 0; i < k; i++) {
+    double *o = out + 14 * i; const hitpoint_t *h = &tmp[i];
+    o[0] = h->pixel; o[1] = h->path; o[2] = h->pt.x; o[3] = h->pt.y; o[4] = h->pt.z; o[5] = h->norm.x; o[6] = h->norm.y; o[7] = h->norm.z;
+    o[8] = h->wgt; o[9] = h->R; o[10] = h->N; o[11] = h->tau.r; o[12] = h->tau.g; o[13] = h->tau.b;
+  }
+  free(tmp);
+}
+void orc_ppm_picture(const orc_ppm *m, double *rgb)
+{ const size_t n = (size_t)m->cam.W * m->cam.H * 3; for (size_t i = 0; i < n; i++) rgb[i] = m->picture[i]; }
+void orc_ppm_counters(const orc_ppm *m, int64_t out[2]) { out[0] = m->photon_segments; out[1] = m->photon_hits; }
+void orc_ppm_end(orc_ppm *m) { if (!m) return; kd_free(m->root); free(m->hps); free(m->picture); free(m); }
+
 void orc_trace_closest(orc_scene *s, const double *rays, size_t n, int use_bsp, int record,
                        int32_t *out_id, double *out_pt, double *out_uv)
 {

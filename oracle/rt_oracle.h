@@ -104,6 +104,20 @@ void orc_render_focusing(orc_scene *s, const orc_camera *c, double radius, int s
                          uint64_t seed, double *rgb, size_t first, size_t count, int threads,
                          int64_t *counters);
 
+/* Progressive photon mapping: Camera.h:291-313 Render_PhotonMapper + PhotonMapper.h.  begin = eye pass
+ * (RayTracingPass per pixel, hit points on diffuse surfaces) + hit-point kd-tree; pass = one iteration of
+ * PhotonMappingPass (emit photon_num photons per light [x sampleNum^2 for an area light], trace, gather, update).
+ * rand() is replaced by the counter generator keyed (seed, pass, photon index, draw number). */
+typedef struct orc_ppm orc_ppm;
+orc_ppm *orc_ppm_begin(orc_scene *s, const orc_camera *c, const double bg[3], uint64_t seed, int photon_num, int times);
+void orc_ppm_pass(orc_ppm *m, int pass_index);
+size_t orc_ppm_num_hitpoints(const orc_ppm *m);
+/* sorted by (pixel, ray-tree path); 14 doubles each: pixel, path, pt[3], norm[3], wgt, R, N, tau[3] */
+void orc_ppm_hitpoints(const orc_ppm *m, double *out);
+void orc_ppm_picture(const orc_ppm *m, double *rgb /* W*H*3, the CV_8UC3 picture as R,G,B */);
+void orc_ppm_counters(const orc_ppm *m, int64_t out[2] /* photon path segments, photon hits on diffuse surfaces */);
+void orc_ppm_end(orc_ppm *m);
+
 /* single primitive known-answer helper: hit point of object id for one ray (recorded variant) */
 void orc_object_first_inter_pt(orc_scene *s, int id, const double ray[6], double out_pt[3], double out_uv[2]);
 

@@ -127,6 +127,16 @@ hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Pa
 hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_render_focusing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp]
 hip.rt_hip_render_focusing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
+hip.rt_hip_ppm_begin.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.c_uint32, C.c_uint32, C.POINTER(_vp)]
+hip.rt_hip_ppm_info.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+hip.rt_hip_ppm_trace.argtypes = [_vp, C.c_uint32, C.c_uint64, C.c_uint64, _vp]
+hip.rt_hip_ppm_accumulators.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_uint64)]
+hip.rt_hip_ppm_update.argtypes = [_vp, _vp]
+hip.rt_hip_ppm_pass.argtypes = [_vp, C.c_uint32]
+hip.rt_hip_ppm_resolve.argtypes = [_vp, _vp]
+hip.rt_hip_ppm_resolve_dev.argtypes = [_vp, _vp, _vp]
+hip.rt_hip_ppm_hitpoints.argtypes = [_vp, _vp]
+hip.rt_hip_ppm_end.argtypes = [_vp]
 hip.rt_hip_scene_share.argtypes = [_vp, C.POINTER(_vp)]
 hip.rt_hip_scene_destroy.argtypes = [_vp]
 hip.rt_hip_set_profiling.argtypes = [_vp, C.c_int]
@@ -188,6 +198,55 @@ class Context:
         if getattr(self, "_h", None):
             host.rth_context_free(self._h)
             self._h = None
+
+
+class PhotonMap:
+    """CPhotonMapper driven as in CCamera::Render_PhotonMapper (Camera.h:291-313) through rt_hip_ppm_*"""
+
+    def __init__(self, ctx, scene, camera, photon_num=50000, times=1, background=(0, 0, 0), seed=0):
+        self._scene, self._ctx, self._cam = scene, ctx, camera
+        self.raw = _vp()
+        p = Params(background=background, seed=seed)
+        check(hip.rt_hip_ppm_begin(scene.device(ctx), camera.raw, p, photon_num, times, C.byref(self.raw)))
+        self.width, self.height = camera.width, camera.height
+
+    def info(self):
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(hip.rt_hip_ppm_info(self.raw, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(hitpoints=a.value, photons_per_pass=b.value, photon_segments=c.value, photon_hits=d.value)
+
+    def run_pass(self, index):
+        check(hip.rt_hip_ppm_pass(self.raw, index))
+
+    def trace(self, index, first=0, count=0, stream=None):
+        check(hip.rt_hip_ppm_trace(self.raw, index, first, count, stream))
+
+    def update(self, stream=None):
+        check(hip.rt_hip_ppm_update(self.raw, stream))
+
+    def accumulators(self):
+        p, n = _vp(), C.c_uint64()
+        check(hip.rt_hip_ppm_accumulators(self.raw, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def picture(self):
+        out = np.zeros((self.width * self.height, 3))
+        check(hip.rt_hip_ppm_resolve(self.raw, out.ctypes.data))
+        return out
+
+    def hitpoints(self):
+        """(n, 11): pixel, path, pt[3], norm[3], wgt, R, N sorted by (pixel, path)"""
+        n = self.info()["hitpoints"]
+        out = np.zeros((n, 11))
+        if n:
+            check(hip.rt_hip_ppm_hitpoints(self.raw, out.ctypes.data))
+            out = out[np.lexsort((out[:, 1], out[:, 0]))]
+        return out
+
+    def __del__(self):
+        if getattr(self, "raw", None):
+            hip.rt_hip_ppm_end(self.raw)
+            self.raw = None
 
 
 class SharedScene:

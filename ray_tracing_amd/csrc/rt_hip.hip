@@ -80,6 +80,9 @@ struct rt_hip_scene {
   DevBuf counter;                 // queue counter + per-render ray counters
   DevBuf staging;                 // host-pointer entry points
   uint64_t last_rays = 0, last_shadow = 0;
+  unsigned int last_n_level[kMaxLevels] = {0}; int last_level = 0;   // sizes of the level arrays of the last run
+  bool keep_uv = false;            // photon mapping eye pass: keep the (u, v) of every node's hit (k_shade overwrites them)
+  DevBuf uv[kMaxLevels];
   // optional per-kernel timing (rt_hip_set_profiling)
   bool prof_on = false;
   struct EvPair { hipEvent_t a, b; int k; };
@@ -644,7 +647,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_shadow(De
 template <bool PARAM>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, PathNode *nodes, unsigned int n, int depth_left,
                                                      const double *lum, PathNode *next, unsigned int next_cap, RenderCounters *cnt,
-                                                     double *direct_rgb, int32_t *direct_id)
+                                                     double *direct_rgb, int32_t *direct_id, double *uv_out)
 {
   const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
   const bool in_range = i < n;
@@ -660,6 +663,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, P
   bool want_refr = false, want_refl = false; V3 dir_refr = mk(0, 0, 0), dir_refl = mk(0, 0, 0);
   if (hit) {
     c = local_illumination<PARAM>(sc, d, nd.id, pt, lum + (size_t)i * sc.n_lights, N, nd.col[0], nd.col[1]);   // col[0..1] = (u, v) until here
+    if (PARAM && uv_out) { uv_out[2 * (size_t)i] = nd.col[0]; uv_out[2 * (size_t)i + 1] = nd.col[1]; }
     if (depth_left > 1) {
       const DMaterial M = sc.materials[sc.obj_mat[nd.id]];
       double refrW = M.refrW, reflW = M.reflW;
@@ -822,6 +826,7 @@ extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
   s->geo.reset();
   for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &b : s->levels) b.release();
+  for (auto &b : s->uv) b.release();
   s->counter.release(); s->staging.release(); s->lum.release(); s->order.release();
   delete s;
   return RT_HIP_OK;
@@ -1177,10 +1182,12 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     {
       ProfScope ps(s, RT_HIP_K_SHADE, st);
       const bool direct = direct_rgb && lv == 0 && depth == 1;
+      double *uv_out = nullptr;
+      if (s->keep_uv && param) { rc = s->uv[lv].ensure((size_t)n * 16); if (rc) return rc; uv_out = (double *)s->uv[lv].p; }
       if (param) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt,
-                                    direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr);
+                                    direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr, uv_out);
       else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt,
-                              direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr);
+                              direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr, (double *)nullptr);
     }
     HIP_TRY(hipGetLastError());
     if (depth_left > 1) {
@@ -1196,6 +1203,8 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
                        (const PathNode *)s->levels[lv + 1].p, A);
     HIP_TRY(hipGetLastError());
   }
+  for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) s->last_n_level[lv] = (lv <= last) ? n_level[lv] : 0;
+  s->last_level = last;
   uint64_t rays = A.pixel_count * A.n_samples; for (int lv = 1; lv <= last; lv++) rays += n_level[lv];
   s->last_rays += rays;
   return RT_HIP_OK;
@@ -1300,3 +1309,5 @@ extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *
   if (shadow_rays) *shadow_rays = c.shadow_rays;
   return RT_HIP_OK;
 }
+
+#include "rt_ppm.inc"

@@ -45,6 +45,15 @@ L.orc_camera_size.argtypes = [C.POINTER(OrcCamera), C.POINTER(C.c_int), C.POINTE
 L.orc_camera_rays.argtypes = [C.POINTER(OrcCamera), _vp]
 L.orc_render_whitted.argtypes = [_vp, C.POINTER(OrcCamera), d3, C.c_uint64, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]
 L.orc_render_focusing.argtypes = [_vp, C.POINTER(OrcCamera), C.c_double, C.c_int, d3, C.c_uint64, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]
+L.orc_ppm_begin.argtypes = [_vp, C.POINTER(OrcCamera), d3, C.c_uint64, C.c_int, C.c_int]
+L.orc_ppm_begin.restype = _vp
+L.orc_ppm_pass.argtypes = [_vp, C.c_int]
+L.orc_ppm_num_hitpoints.argtypes = [_vp]
+L.orc_ppm_num_hitpoints.restype = C.c_size_t
+L.orc_ppm_hitpoints.argtypes = [_vp, _vp]
+L.orc_ppm_picture.argtypes = [_vp, _vp]
+L.orc_ppm_counters.argtypes = [_vp, _vp]
+L.orc_ppm_end.argtypes = [_vp]
 L.orc_object_first_inter_pt.argtypes = [_vp, C.c_int, _vp, _vp, _vp]
 
 MATERIALS = {"mirror": 200, "glass": 201, "ice": 202, "metal": 203, "porcelain": 204, "rubber": 205, "plastic": 206}
@@ -169,4 +178,40 @@ class OracleScene:
     def __del__(self):
         if getattr(self, "h", None):
             L.orc_scene_free(self.h)
+            self.h = None
+
+
+class OraclePhotonMap:
+    """orc_ppm_*: Camera.h:291-313 + PhotonMapper.h on the CPU"""
+
+    def __init__(self, scene, cam, photon_num=50000, times=1, background=(0, 0, 0), seed=0):
+        self._scene = scene
+        w, h = C.c_int(), C.c_int()
+        L.orc_camera_size(C.byref(cam), C.byref(w), C.byref(h))
+        self.width, self.height = w.value, h.value
+        self.h = L.orc_ppm_begin(scene.h, C.byref(cam), d3(*background), seed, photon_num, times)
+
+    def run_pass(self, index):
+        L.orc_ppm_pass(self.h, index)
+
+    def hitpoints(self):
+        n = L.orc_ppm_num_hitpoints(self.h)
+        out = np.zeros((n, 14))
+        if n:
+            L.orc_ppm_hitpoints(self.h, out.ctypes.data)
+        return out
+
+    def picture(self):
+        out = np.zeros((self.width * self.height, 3))
+        L.orc_ppm_picture(self.h, out.ctypes.data)
+        return out
+
+    def counters(self):
+        c = np.zeros(2, np.int64)
+        L.orc_ppm_counters(self.h, c.ctypes.data)
+        return dict(photon_segments=int(c[0]), photon_hits=int(c[1]))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            L.orc_ppm_end(self.h)
             self.h = None

@@ -351,3 +351,89 @@ def test_c5_wine_image_parity(ctx):
     assert (ids_ref >= 3).sum() > 300
     assert bad.mean() <= 1e-4
     assert off.mean() <= 2e-3
+
+
+# ---- progressive photon mapping ------------------------------------------------------------------------
+def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp):
+    import oracle_bind as ob
+    import ray_tracing_amd as rta
+    cam = rta.Camera(**cam_args)
+    gm = rta.PhotonMap(ctx, g, cam, photon_num=photon_num, times=times, background=(10, 10, 10), seed=5)
+    om = ob.OraclePhotonMap(o, scenes.oracle_camera(cam_args), photon_num=photon_num, times=times, background=(10, 10, 10), seed=5)
+    # eye pass: same hit points (pixel, ray-tree path), same positions, normals and weights; same picture
+    gh, oh = gm.hitpoints(), om.hitpoints()
+    assert gh.shape[0] == oh.shape[0] >= min_hp
+    assert (gh[:, :2] == oh[:, :2]).all()
+    assert np.abs(gh[:, 2:9] - oh[:, 2:9]).max() < 1e-6
+    pic_g, pic_o = gm.picture(), om.picture()
+    d0 = np.abs(pic_g - pic_o)
+    assert d0.max() <= 1 and (d0 > 0).mean() < 1e-3          # uchar truncation of doubles that agree to ~1e-13
+    for t in range(times):
+        gm.run_pass(t)
+        om.run_pass(t)
+        gh, oh = gm.hitpoints(), om.hitpoints()
+        # N = alpha * (photons gathered so far): a photon on the rim of a gather disc (|dist - R| ~ 1e-13) may fall either side
+        dN = np.abs(gh[:, 10] - oh[:, 10])
+        dR = np.abs(gh[:, 9] - oh[:, 9])
+        print("%s pass %d: hit points %d, N total %.1f vs %.1f, hit points with different N %d, max |dR| %.3g" % (
+            what, t, gh.shape[0], gh[:, 10].sum(), oh[:, 10].sum(), int((dN > 1e-9).sum()), dR.max()))
+        assert (dN > 1e-9).mean() < 1e-3
+        assert dR[dN <= 1e-9].max() < 1e-9
+    info, oc = gm.info(), om.counters()
+    print("%s: photons/pass %d, segments %d vs %d, photon hits %d vs %d" % (what, info["photons_per_pass"], info["photon_segments"],
+                                                                         oc["photon_segments"], info["photon_hits"], oc["photon_hits"]))
+    assert abs(info["photon_segments"] - oc["photon_segments"]) <= 1e-4 * oc["photon_segments"]
+    assert abs(info["photon_hits"] - oc["photon_hits"]) <= 1e-4 * oc["photon_hits"]
+    pic_g, pic_o = gm.picture(), om.picture()
+    d = np.abs(pic_g - pic_o)
+    print("%s: picture max |diff| %d, pixels differing %d of %d, mean added %.2f" % (what, d.max(), int((d.max(axis=1) > 0).sum()), d.shape[0],
+                                                                             (pic_o.sum() - 0) / pic_o.size))
+    # Vec3b(tau) truncates: a tau within rounding noise of an integer may land on either side, once per pass and hit point
+    assert d.max() <= times and (d.max(axis=1) > 0).mean() < 5e-3
+    return gm, om
+
+
+def test_ppm_icosahedron_scene(ctx):
+    """photon mapping on the C1 scene (triangles in a BSP tree, diffuse + mirror + glass), point-like area light"""
+    g, o = scenes.build_icosahedron(material="plastic", light="point_area", extra_sphere=True)
+    cam_args = dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=30, depth=3)
+    _ppm_compare(ctx, g, o, cam_args, photon_num=20000, times=2, what="ppm C1", min_hp=5000)
+
+
+def test_ppm_area_light_emission(ctx):
+    """area light emission (photonNum x sampleNum^2 photons per pass, PhotonMapper.h:251-268)"""
+    g, o = scenes.build_icosahedron(material="rubber", light="area3")
+    cam_args = dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=20, depth=1)
+    gm, om = _ppm_compare(ctx, g, o, cam_args, photon_num=3000, times=1, what="ppm area", min_hp=2000)
+    assert gm.info()["photons_per_pass"] == 3000 * 9
+
+
+def test_ppm_wine_scene(ctx):
+    """C5 geometry (no tree, surfaces of revolution, glass and ice) with its area light, reduced sizes"""
+    g, o = scenes.build_wine(light="area")
+    cam_args = dict(scenes.C5_CAMERA, res=10, depth=4)
+    _ppm_compare(ctx, g, o, cam_args, photon_num=1500, times=2, what="ppm C5", min_hp=2000)
+
+
+def test_ppm_photon_shards_add_up(ctx):
+    """multi-GPU hook: a pass traced as three photon ranges gives the accumulators of the pass traced at once"""
+    import torch
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(material="plastic", light="point_area", extra_sphere=True, oracle=False)
+    cam = rta.Camera(**dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=20, depth=2))
+    a = rta.PhotonMap(ctx, g, cam, photon_num=10000, times=1, seed=3)
+    b = rta.PhotonMap(ctx, g, cam, photon_num=10000, times=1, seed=3)
+    a.trace(0)
+    for first, count in ((0, 3333), (3333, 4000), (7333, 2667)):
+        b.trace(0, first, count)
+    torch.cuda.synchronize()
+    import ctypes as C
+    pa, na = a.accumulators(); pb, nb = b.accumulators()
+    assert na == nb
+    ha, hb = np.zeros(na), np.zeros(nb)
+    for ptr, host in ((pa, ha), (pb, hb)):
+        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), C.c_size_t(na * 8), 2)
+    acc_a, acc_b = ha.reshape(-1, 4), hb.reshape(-1, 4)
+    assert (acc_a[:, 0] == acc_b[:, 0]).all()                       # photon counts: exact
+    assert np.allclose(acc_a[:, 1:], acc_b[:, 1:], rtol=1e-12, atol=1e-12)
+    assert acc_a[:, 0].sum() > 1000
