@@ -230,6 +230,22 @@ int rt_hip_ppm_resolve_dev(rt_hip_ppm *ppm, double *d_rgb, void *stream);
 int rt_hip_ppm_hitpoints(rt_hip_ppm *ppm, double *out /* 11 doubles each: pixel, path, pt[3], norm[3], wgt, R, N */);
 int rt_hip_ppm_end(rt_hip_ppm *ppm);
 
+/* ---- god ray: CGodRay (GodRay.h:109-245) driven as in CCamera::Render_RayTracer_GodRay (Camera.h:425-448).
+ * create = CGodRay(scene, lightColour); add_area_xz = AddAreaLightSource_XZ (:193-200); build = PhotonMappingPass
+ * (:136-140: light-shaft photons + their kd-tree); render = RayTracingPass per pixel (:142-191). ---- */
+typedef struct rt_hip_godray rt_hip_godray;
+int rt_hip_godray_create(rt_hip_scene *scene, const double light_colour[3], uint64_t seed, rt_hip_godray **out);
+int rt_hip_godray_add_area_xz(rt_hip_godray *g, double y, const double min_xz[2], const double max_xz[2], double light_sample_interval,
+                              const double direction[3]);
+int rt_hip_godray_build(rt_hip_godray *g);
+int rt_hip_godray_num_photons(rt_hip_godray *g, uint64_t *n);
+int rt_hip_godray_photons(rt_hip_godray *g, double *out /* 4 per photon: x, y, z, energy; creation order */);
+int rt_hip_render_godray(rt_hip_scene *scene, rt_hip_godray *g, const rt_hip_camera *cam, const rt_hip_params *params, double *rgb,
+                         int32_t *prim_id);
+int rt_hip_render_godray_dev(rt_hip_scene *scene, rt_hip_godray *g, const rt_hip_camera *cam, const rt_hip_params *params, double *d_rgb,
+                             int32_t *d_prim_id, void *stream);
+int rt_hip_godray_destroy(rt_hip_godray *g);
+
 /* Per-kernel device time, measured with hipEvents recorded on the caller's stream around every
  * kernel launch of this scene while profiling is on (rt_hip_set_profiling).  Index = RT_HIP_K_*. */
 #define RT_HIP_K_PRIMARY        0   /* camera/lens ray generation + closest hit (level 0) */

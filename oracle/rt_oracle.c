@@ -973,6 +973,10 @@ typedef struct { v3 pt, norm, omega; int h, v; double wgt, R, N, M; col_t tau; u
 typedef struct { hitpoint_t *a; size_t n, cap; int W; } hp_sink_t;
 static _Thread_local hp_sink_t *tl_hp = NULL;      /* non-NULL: ray_tracer is CPhotonMapper::RayTracingPass (PhotonMapper.h:159-220) */
 
+struct orc_godray;
+static _Thread_local const struct orc_godray *tl_god = NULL;   /* non-NULL: ray_tracer is CGodRay::RayTracingPass (GodRay.h:142-191) */
+static col_t god_radiance(const struct orc_godray *g, ray_t ray);
+
 static const double THRESHOLD = 0.1;                                      /* RayTracer.h:7 */
 static col_t ray_tracer(orc_scene *s, ray_t ray, int depth, double weight, col_t bg, rng_ctx g,
                         int32_t *first_id)
@@ -983,7 +987,8 @@ static col_t ray_tracer(orc_scene *s, ray_t ray, int depth, double weight, col_t
   if (first_id) *first_id = in.obj;
   if (in.obj < 0) return bg;
   const obj_t *o = &s->objs[in.obj];
-  colour = local_illumination(s, ray, in, &g);
+  if (tl_god) colour = c_add(colour, god_radiance(tl_god, ray));           /* GodRay.h:155 */
+  colour = c_add(colour, local_illumination(s, ray, in, &g));            /* GodRay.h:157 / RayTracer.h:21 (0 + x: the clamp is the same) */
   if (tl_hp && o->mat.reflW == 0 && o->mat.refrW == 0) {                  /* PhotonMapper.h:174-186 */
     hp_sink_t *k = tl_hp;
     if (k->n == k->cap) { k->cap = k->cap ? k->cap * 2 : 1024; k->a = (hitpoint_t *)realloc(k->a, k->cap * sizeof(hitpoint_t)); }
@@ -1377,6 +1382,151 @@ void orc_ppm_picture(const orc_ppm *m, double *rgb)
 { const size_t n = (size_t)m->cam.W * m->cam.H * 3; for (size_t i = 0; i < n; i++) rgb[i] = m->picture[i]; }
 void orc_ppm_counters(const orc_ppm *m, int64_t out[2]) { out[0] = m->photon_segments; out[1] = m->photon_hits; }
 void orc_ppm_end(orc_ppm *m) { if (!m) return; kd_free(m->root); free(m->hps); free(m->picture); free(m); }
+
+
+/* ------------------------------------------------------------------ god ray (GodRay.h, Camera.h:425-448) */
+typedef struct { v3 pos; double energy; uint32_t idx; } god_photon_t;     /* CGodPhoton, :18-24 (+ creation index: sort tie-break) */
+typedef struct god_node { god_photon_t ph; int split_axis; struct god_node *l, *r; } god_node;
+typedef struct { v3 pos, dir; } god_source_t;                             /* CLightSource, :9-15 */
+struct orc_godray {
+  orc_scene *s; col_t light_colour; uint64_t seed;
+  god_source_t *src; size_t n_src, cap_src; uint32_t n_areas;
+  god_photon_t *ph; size_t n_ph, cap_ph;
+  god_node *root;
+};
+static const double GOD_RADIUS = 0.1, GOD_INTERVAL = 0.05, GOD_DECAY = 0.95, GOD_E0 = 0.01;   /* :128-131 */
+
+static inline double god_random(double r, int x, uint64_t seed, uint32_t k0, uint32_t k1, uint32_t draw)
+{ uint32_t k = orc_rng_u32(seed, k0, k1, draw) >> 1; return 2 * r * (double)(k % (uint32_t)x) / (double)x - r; }
+
+orc_godray *orc_godray_new(orc_scene *s, const double light_colour[3], uint64_t seed)
+{
+  orc_godray *g = (orc_godray *)calloc(1, sizeof *g);
+  g->s = s; g->light_colour = C3(light_colour[0], light_colour[1], light_colour[2]); g->seed = seed;
+  return g;
+}
+/* CGodRay::AddAreaLightSource_XZ, :193-200; jitter draws in x, z order (pinned) */
+void orc_godray_add_area_xz(orc_godray *g, double y, const double mn[2], const double mx[2], double interval, const double dir[3])
+{
+  uint32_t k = 0;
+  for (double x = mn[0]; x < mx[0]; x += interval)
+    for (double z = mn[1]; z < mx[1]; z += interval, k++) {
+      if (g->n_src == g->cap_src) { g->cap_src = g->cap_src ? g->cap_src * 2 : 1024; g->src = (god_source_t *)realloc(g->src, g->cap_src * sizeof(god_source_t)); }
+      double jx = god_random(interval / 3, 10000, g->seed ^ 0x474F4453ULL, g->n_areas, k, 0);
+      double jz = god_random(interval / 3, 10000, g->seed ^ 0x474F4453ULL, g->n_areas, k, 1);
+      g->src[g->n_src].pos = V3(x + jx, y, z + jz); g->src[g->n_src].dir = V3(dir[0], dir[1], dir[2]);
+      g->n_src++;
+    }
+  g->n_areas++;
+}
+static int god_axis;
+static int cmp_god(const void *a, const void *b)
+{
+  const god_photon_t *x = (const god_photon_t *)a, *y = (const god_photon_t *)b;
+  double p = god_axis == 0 ? x->pos.x : (god_axis == 1 ? x->pos.y : x->pos.z), q = god_axis == 0 ? y->pos.x : (god_axis == 1 ? y->pos.y : y->pos.z);
+  if (p < q) return -1;
+  if (q < p) return 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);   /* std::sort leaves ties unspecified: creation order here and in the library */
+}
+/* CPhotonTree::BuildTree, :52-105 */
+static god_node *god_build(god_photon_t *h, size_t n)
+{
+  if (n == 0) return NULL;
+  god_node *node = (god_node *)calloc(1, sizeof *node);
+  if (n == 1) { node->ph = h[0]; node->split_axis = 0; return node; }
+  double mx = 0, my = 0, mz = 0, vx = 0, vy = 0, vz = 0;
+  for (size_t i = 0; i < n; i++) { mx += h[i].pos.x; my += h[i].pos.y; mz += h[i].pos.z; }
+  mx /= (double)n; my /= (double)n; mz /= (double)n;
+  for (size_t i = 0; i < n; i++) {
+    vx += (h[i].pos.x - mx) * (h[i].pos.x - mx); vy += (h[i].pos.y - my) * (h[i].pos.y - my); vz += (h[i].pos.z - mz) * (h[i].pos.z - mz);
+  }
+  if (vx >= vy && vx >= vz) node->split_axis = 0; else if (vy >= vx && vy >= vz) node->split_axis = 1; else node->split_axis = 2;
+  god_axis = node->split_axis;
+  qsort(h, n, sizeof *h, cmp_god);
+  node->ph = h[n / 2];
+  node->l = god_build(h, n / 2);
+  if (n >= 3) node->r = god_build(h + n / 2 + 1, n - n / 2 - 1);
+  return node;
+}
+static void god_free(god_node *n) { if (!n) return; god_free(n->l); god_free(n->r); free(n); }
+
+/* CGodRay::PhotonMappingPass = GeneratePhotons (:202-215) + ConstructPhotonTree */
+void orc_godray_build(orc_godray *g)
+{
+  for (size_t i = 0; i < g->n_src; i++) {
+    ray_t ray = mk_ray(g->src[i].pos, g->src[i].dir);
+    v3 pt = first_inter_pt_bsp(g->s, ray, 0).pt;
+    double t_range = dmin(v_dist(g->src[i].pos, pt), 10.0);
+    uint32_t draw = 0;
+    for (double t = 0, a = 1; t < t_range; t += GOD_INTERVAL, a *= GOD_DECAY) {
+      t += god_random(GOD_INTERVAL / 3, 10000, g->seed ^ 0x474F4450ULL, (uint32_t)i, 0, draw++);
+      if (g->n_ph == g->cap_ph) { g->cap_ph = g->cap_ph ? g->cap_ph * 2 : 4096; g->ph = (god_photon_t *)realloc(g->ph, g->cap_ph * sizeof(god_photon_t)); }
+      g->ph[g->n_ph].pos = v_add(g->src[i].pos, v_mul(g->src[i].dir, t));      /* the direction is NOT unitized here (:212) */
+      g->ph[g->n_ph].energy = GOD_E0 * a; g->ph[g->n_ph].idx = (uint32_t)g->n_ph;
+      g->n_ph++;
+    }
+  }
+  god_photon_t *tmp = (god_photon_t *)malloc((g->n_ph + 1) * sizeof(god_photon_t));
+  memcpy(tmp, g->ph, g->n_ph * sizeof(god_photon_t));
+  g->root = god_build(tmp, g->n_ph);
+  free(tmp);
+}
+size_t orc_godray_num_photons(const orc_godray *g) { return g->n_ph; }
+void orc_godray_photons(const orc_godray *g, double *out /* 4 per photon: x, y, z, energy, creation order */)
+{ for (size_t i = 0; i < g->n_ph; i++) { out[4 * i] = g->ph[i].pos.x; out[4 * i + 1] = g->ph[i].pos.y; out[4 * i + 2] = g->ph[i].pos.z; out[4 * i + 3] = g->ph[i].energy; } }
+
+/* CRay::Dist, Geometry.h:265-272: distance to the infinite LINE through the ray */
+static inline double ray_line_dist(ray_t ray, v3 pt)
+{ v3 l = v_sub(pt, ray.o); double tp = v_dot(l, ray.d); double d2 = v_len2(l) - tp * tp; return sqrt(d2); }
+/* CGodRay::RadianceEvaluation, :217-245 */
+static col_t god_eval(const orc_godray *g, const god_node *node, ray_t ray)
+{
+  if (!node) return C3(0, 0, 0);
+  col_t colour = C3(0, 0, 0);
+  if (ray_line_dist(ray, node->ph.pos) < GOD_RADIUS) colour = c_add(colour, c_mul(g->light_colour, node->ph.energy));
+  v3 p0 = node->ph.pos;
+  v3 normal = V3(0, 0, 0);
+  if (node->split_axis == 0) normal.x = 1;
+  if (node->split_axis == 1) normal.y = 1;
+  if (node->split_axis == 2) normal.z = 1;
+  const god_node *near_n, *far_n;
+  if (v_dot(v_sub(p0, ray.o), normal) > 0) { near_n = node->l; far_n = node->r; }
+  else { near_n = node->r; far_n = node->l; normal = v_neg(normal); }
+  colour = c_add(colour, god_eval(g, near_n, ray));
+  if (v_dot(ray.d, normal) > -EPS || fabs(v_dot(v_sub(p0, ray.o), normal)) < GOD_RADIUS + EPS)
+    colour = c_add(colour, god_eval(g, far_n, ray));
+  return colour;
+}
+static col_t god_radiance(const struct orc_godray *g, ray_t ray) { return god_eval(g, g->root, ray); }
+
+/* Camera.h:425-448 Render_RayTracer_GodRay after PhotonMappingPass: rgb NOT truncated (like orc_render_whitted) */
+void orc_render_godray(orc_godray *g, const orc_camera *c, const double bg[3], double *rgb, int32_t *prim_id)
+{
+  cam_t k = cam_init(c);
+  const size_t total = (size_t)k.W * k.H;
+  col_t bgc = C3(bg[0], bg[1], bg[2]);
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    tl_god = g;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 64)
+#endif
+    for (long long p = 0; p < (long long)total; p++) {
+      int v = (int)(p / k.W), h = (int)(p % k.W);
+      v3 cur = cam_cur_pt(&k, h, v);
+      ray_t ray = mk_ray(k.view_pt, v_unitize(v_sub(cur, k.view_pt)));
+      rng_ctx rg; rg.seed = g->seed; rg.pixel = (uint32_t)p; rg.sample = 0; rg.path = 1;
+      int32_t id = -1;
+      col_t col = ray_tracer(g->s, ray, k.depth, 1, bgc, rg, &id);
+      rgb[3 * p] = col.r; rgb[3 * p + 1] = col.g; rgb[3 * p + 2] = col.b;
+      if (prim_id) prim_id[p] = id;
+    }
+    tl_god = NULL;
+  }
+}
+void orc_godray_free(orc_godray *g) { if (!g) return; god_free(g->root); free(g->src); free(g->ph); free(g); }
 
 void orc_trace_closest(orc_scene *s, const double *rays, size_t n, int use_bsp, int record,
                        int32_t *out_id, double *out_pt, double *out_uv)

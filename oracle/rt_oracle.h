@@ -118,6 +118,17 @@ void orc_ppm_picture(const orc_ppm *m, double *rgb /* W*H*3, the CV_8UC3 picture
 void orc_ppm_counters(const orc_ppm *m, int64_t out[2] /* photon path segments, photon hits on diffuse surfaces */);
 void orc_ppm_end(orc_ppm *m);
 
+/* God ray: GodRay.h + Camera.h:425-448.  add_area_xz = AddAreaLightSource_XZ, build = PhotonMappingPass (light-shaft photons
+ * + their kd-tree), render = Render_RayTracer_GodRay (Whitted + the photons within 0.1 of the line of every ray). */
+typedef struct orc_godray orc_godray;
+orc_godray *orc_godray_new(orc_scene *s, const double light_colour[3], uint64_t seed);
+void orc_godray_add_area_xz(orc_godray *g, double y, const double mn[2], const double mx[2], double interval, const double dir[3]);
+void orc_godray_build(orc_godray *g);
+size_t orc_godray_num_photons(const orc_godray *g);
+void orc_godray_photons(const orc_godray *g, double *out /* 4 per photon: x, y, z, energy; creation order */);
+void orc_render_godray(orc_godray *g, const orc_camera *c, const double bg[3], double *rgb, int32_t *prim_id);
+void orc_godray_free(orc_godray *g);
+
 /* single primitive known-answer helper: hit point of object id for one ray (recorded variant) */
 void orc_object_first_inter_pt(orc_scene *s, int id, const double ray[6], double out_pt[3], double out_uv[2]);
 

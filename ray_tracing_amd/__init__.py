@@ -127,6 +127,14 @@ hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Pa
 hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_render_focusing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp]
 hip.rt_hip_render_focusing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
+hip.rt_hip_godray_create.argtypes = [_vp, d3, C.c_uint64, C.POINTER(_vp)]
+hip.rt_hip_godray_add_area_xz.argtypes = [_vp, C.c_double, C.c_double * 2, C.c_double * 2, C.c_double, d3]
+hip.rt_hip_godray_build.argtypes = [_vp]
+hip.rt_hip_godray_num_photons.argtypes = [_vp, C.POINTER(C.c_uint64)]
+hip.rt_hip_godray_photons.argtypes = [_vp, _vp]
+hip.rt_hip_render_godray.argtypes = [_vp, _vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
+hip.rt_hip_render_godray_dev.argtypes = [_vp, _vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
+hip.rt_hip_godray_destroy.argtypes = [_vp]
 hip.rt_hip_ppm_begin.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.c_uint32, C.c_uint32, C.POINTER(_vp)]
 hip.rt_hip_ppm_info.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 hip.rt_hip_ppm_trace.argtypes = [_vp, C.c_uint32, C.c_uint64, C.c_uint64, _vp]
@@ -198,6 +206,42 @@ class Context:
         if getattr(self, "_h", None):
             host.rth_context_free(self._h)
             self._h = None
+
+
+class GodRay:
+    """CGodRay (GodRay.h:109-245) through rt_hip_godray_*"""
+
+    def __init__(self, ctx, scene, light_colour, seed=0):
+        self._scene, self._ctx, self.seed = scene, ctx, seed
+        self.raw = _vp()
+        check(hip.rt_hip_godray_create(scene.device(ctx), d3(*light_colour), seed, C.byref(self.raw)))
+
+    def add_area_light_source_xz(self, y, mn, mx, interval, direction):
+        check(hip.rt_hip_godray_add_area_xz(self.raw, y, (C.c_double * 2)(*mn), (C.c_double * 2)(*mx), interval, d3(*direction)))
+
+    def photon_mapping_pass(self):
+        check(hip.rt_hip_godray_build(self.raw))
+
+    def photons(self):
+        n = C.c_uint64()
+        check(hip.rt_hip_godray_num_photons(self.raw, C.byref(n)))
+        out = np.zeros((n.value, 4))
+        if n.value:
+            check(hip.rt_hip_godray_photons(self.raw, out.ctypes.data))
+        return out
+
+    def render(self, camera, background=(0, 0, 0)):
+        """CCamera::Render_RayTracer_GodRay: (rgb (n,3) doubles, prim ids)"""
+        n = camera.width * camera.height
+        rgb = np.zeros((n, 3)); ids = np.zeros(n, np.int32)
+        p = Params(background=background, seed=self.seed)        # area-light shadow samples
+        check(hip.rt_hip_render_godray(self._scene.device(self._ctx), self.raw, camera.raw, p, rgb.ctypes.data, ids.ctypes.data))
+        return rgb, ids
+
+    def __del__(self):
+        if getattr(self, "raw", None):
+            hip.rt_hip_godray_destroy(self.raw)
+            self.raw = None
 
 
 class PhotonMap:

@@ -66,8 +66,10 @@ struct alignas(16) PathNode {
 };
 static_assert(sizeof(PathNode) == 128, "PathNode layout");
 
+struct rt_hip_godray;
 struct rt_hip_scene {
   rt_hip_ctx *ctx = nullptr;
+  rt_hip_godray *god = nullptr;    // set for the duration of rt_hip_render_godray: run_levels adds the light-shaft radiance
   DevScene dev{};
   // scene arrays in HBM; shared (read-only) by the handles made with rt_hip_scene_share
   struct Geometry { std::vector<void *> allocs; ~Geometry() { for (void *p : allocs) (void)hipFree(p); } };
@@ -1117,6 +1119,8 @@ extern "C" int rt_hip_camera_size(const rt_hip_camera *cam, int *w, int *h)
   return RT_HIP_OK;
 }
 
+static int godray_level(rt_hip_scene *s, PathNode *nodes, unsigned int n, hipStream_t st);   // rt_godray.inc
+
 // the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
 static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, double *direct_rgb = nullptr, int32_t *direct_id = nullptr)
 {
@@ -1189,6 +1193,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
       else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt,
                               direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr, (double *)nullptr);
     }
+    if (s->god) { rc = godray_level(s, cur, n, st); if (rc) return rc; }
     HIP_TRY(hipGetLastError());
     if (depth_left > 1) {
       unsigned int qn = 0;
@@ -1311,3 +1316,4 @@ extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *
 }
 
 #include "rt_ppm.inc"
+#include "rt_godray.inc"

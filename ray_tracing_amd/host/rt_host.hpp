@@ -369,6 +369,28 @@ class Scene {                    // CScene, Scene.h:12-60
   rt_hip_scene *dev_ = nullptr; rt_hip_ctx *dev_ctx_ = nullptr; bool dirty_ = true;
 };
 
+class GodRay {                   // CGodRay, GodRay.h:109-134
+ public:
+  GodRay(Context &ctx, Scene &scene, Colour lightColour, uint64_t seed = 0) : scene_(scene.Device(ctx))
+  {
+    const double c[3] = {lightColour.R, lightColour.G, lightColour.B};
+    check(rt_hip_godray_create(scene_, c, seed, &g_), "rt_hip_godray_create");
+  }
+  ~GodRay() { rt_hip_godray_destroy(g_); }
+  GodRay(const GodRay &) = delete; GodRay &operator=(const GodRay &) = delete;
+  // GodRay.h:193-200; min / max are (x, z) corners
+  void AddAreaLightSource_XZ(double y, const double min_xz[2], const double max_xz[2], double lightSampleInterval, Point3D direction)
+  {
+    const double d[3] = {direction.x, direction.y, direction.z};
+    check(rt_hip_godray_add_area_xz(g_, y, min_xz, max_xz, lightSampleInterval, d), "rt_hip_godray_add_area_xz");
+  }
+  void PhotonMappingPass() { check(rt_hip_godray_build(g_), "rt_hip_godray_build"); }     // GodRay.h:136-140
+  rt_hip_godray *get() const { return g_; }
+  rt_hip_scene *scene() const { return scene_; }
+ private:
+  rt_hip_scene *scene_ = nullptr; rt_hip_godray *g_ = nullptr;
+};
+
 class Camera {                   // CCamera, Camera.h:14-51
  public:
   Camera(Point3D viewPt, Point3D eyeDirection, Point3D left, double distOfPlane, double horRange, double verRange,
@@ -399,6 +421,30 @@ class Camera {                   // CCamera, Camera.h:14-51
     rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.clear();
     check(rt_hip_render_focusing(scene.Device(ctx), &cam_, &p, rgb_.data()), "rt_hip_render_focusing");
     for (double &c : rgb_) c = std::min(255.0, c);        // the running clamp of Colour.h:41-47, applied once
+    to_picture();
+  }
+  // Render_PhotonMapper, Camera.h:291-313: eye pass, then `times` photon passes of photonNum photons per light
+  // (PhotonMapper.h:155: 50000); the picture is the reference's CV_8UC3 image
+  void Render_PhotonMapper(Context &ctx, Scene &scene, int times, Colour background = Colour(0, 0, 0), uint32_t photonNum = 50000)
+  {
+    rt_hip_params p = params(background);
+    rt_hip_ppm *m = nullptr;
+    check(rt_hip_ppm_begin(scene.Device(ctx), &cam_, &p, photonNum, (uint32_t)times, &m), "rt_hip_ppm_begin");
+    int rc = 0;
+    for (int t = 0; t < times && !rc; t++) rc = rt_hip_ppm_pass(m, (uint32_t)t);
+    rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.clear();
+    if (!rc) rc = rt_hip_ppm_resolve(m, rgb_.data());
+    rt_hip_ppm_end(m);
+    check(rc, "rt_hip_ppm_pass");
+    to_picture();
+  }
+  // Render_RayTracer_GodRay, Camera.h:425-448 (the caller runs godRay.PhotonMappingPass() first; the reference does it here)
+  void Render_RayTracer_GodRay(GodRay &godRay, Colour background = Colour(0, 0, 0))
+  {
+    godRay.PhotonMappingPass();
+    rt_hip_params p = params(background);
+    rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.assign((size_t)w_ * h_, -1);
+    check(rt_hip_render_godray(godRay.scene(), godRay.get(), &cam_, &p, rgb_.data(), prim_.data()), "rt_hip_render_godray");
     to_picture();
   }
   const std::vector<double> &rgb() const { return rgb_; }

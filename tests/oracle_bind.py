@@ -45,6 +45,15 @@ L.orc_camera_size.argtypes = [C.POINTER(OrcCamera), C.POINTER(C.c_int), C.POINTE
 L.orc_camera_rays.argtypes = [C.POINTER(OrcCamera), _vp]
 L.orc_render_whitted.argtypes = [_vp, C.POINTER(OrcCamera), d3, C.c_uint64, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]
 L.orc_render_focusing.argtypes = [_vp, C.POINTER(OrcCamera), C.c_double, C.c_int, d3, C.c_uint64, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]
+L.orc_godray_new.argtypes = [_vp, d3, C.c_uint64]
+L.orc_godray_new.restype = _vp
+L.orc_godray_add_area_xz.argtypes = [_vp, C.c_double, C.c_double * 2, C.c_double * 2, C.c_double, d3]
+L.orc_godray_build.argtypes = [_vp]
+L.orc_godray_num_photons.argtypes = [_vp]
+L.orc_godray_num_photons.restype = C.c_size_t
+L.orc_godray_photons.argtypes = [_vp, _vp]
+L.orc_render_godray.argtypes = [_vp, C.POINTER(OrcCamera), d3, _vp, _vp]
+L.orc_godray_free.argtypes = [_vp]
 L.orc_ppm_begin.argtypes = [_vp, C.POINTER(OrcCamera), d3, C.c_uint64, C.c_int, C.c_int]
 L.orc_ppm_begin.restype = _vp
 L.orc_ppm_pass.argtypes = [_vp, C.c_int]
@@ -214,4 +223,38 @@ class OraclePhotonMap:
     def __del__(self):
         if getattr(self, "h", None):
             L.orc_ppm_end(self.h)
+            self.h = None
+
+
+class OracleGodRay:
+    """orc_godray_*: GodRay.h + Camera.h:425-448 on the CPU"""
+
+    def __init__(self, scene, light_colour, seed=0):
+        self._scene = scene
+        self.h = L.orc_godray_new(scene.h, d3(*light_colour), seed)
+
+    def add_area_light_source_xz(self, y, mn, mx, interval, direction):
+        L.orc_godray_add_area_xz(self.h, y, (C.c_double * 2)(*mn), (C.c_double * 2)(*mx), interval, d3(*direction))
+
+    def photon_mapping_pass(self):
+        L.orc_godray_build(self.h)
+
+    def photons(self):
+        n = L.orc_godray_num_photons(self.h)
+        out = np.zeros((n, 4))
+        if n:
+            L.orc_godray_photons(self.h, out.ctypes.data)
+        return out
+
+    def render(self, cam, background=(0, 0, 0)):
+        w, h = C.c_int(), C.c_int()
+        L.orc_camera_size(C.byref(cam), C.byref(w), C.byref(h))
+        n = w.value * h.value
+        rgb = np.zeros((n, 3)); ids = np.zeros(n, np.int32)
+        L.orc_render_godray(self.h, C.byref(cam), d3(*background), rgb.ctypes.data, ids.ctypes.data)
+        return rgb, ids
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            L.orc_godray_free(self.h)
             self.h = None

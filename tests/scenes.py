@@ -193,3 +193,26 @@ def build_wine(gpu=True, oracle=True, cups=((-2, -2, 0),), light="point", cup_ma
     elif light == "area":
         P.call("add_area_light", (-10, 25, 25), 2.0, 2.0, 2)
     return P.g, P.o
+
+
+ROOM_CAMERA = dict(view=(-10, 0, 2.5), eye=(1, 0, 0), left=(0, -1, 0), dist=10, hor=8, ver=6, res=100, depth=1)   # Layout.h:320
+
+
+def build_room(gpu=True, oracle=True, mirror=True):
+    """Layout6_Room (Layout.h:302-323) with a synthetic corridor: Corridor_Triangle.obj is one of the blobs missing from
+    the reference checkout (.MISSING_LARGE_BLOBS), so a floor, a side wall with a window gap and the icosahedron mesh
+    stand in for it.  Light shafts come from an XZ rectangle at y = 6 towards (1,-2,-1) as in Layout.h:317-318."""
+    P = _Pair(0.1, gpu, oracle)
+    plastic = P.mat("plastic")
+    P.call("add_plane", (50, 0, 0), (-1, 0, 0), mat=plastic, colour=(90, 90, 120))
+    def quad(a, b, c, d, mat, colour):
+        P.call("add_triangle", [a, b, c], None, mat=mat, colour=colour)
+        P.call("add_triangle", [a, c, d], None, mat=mat, colour=colour)
+    quad((-12, -8, 0), (30, -8, 0), (30, 8, 0), (-12, 8, 0), plastic, (241, 46, 24))             # floor
+    quad((-12, 5, 0), (2, 5, 0), (2, 5, 8), (-12, 5, 8), plastic, (200, 200, 200))               # wall, left of the window
+    quad((6, 5, 0), (30, 5, 0), (30, 5, 8), (6, 5, 8), plastic, (200, 200, 200))                 # wall, right of the window
+    quad((2, 5, 0), (6, 5, 0), (6, 5, 1), (2, 5, 1), plastic, (200, 200, 200))                   # sill
+    P.call("read_obj_triangle", ICOSA_OBJ, (9, -2, 0), 0.003, mat=P.mat("metal" if mirror else "plastic"), colour=(241, 46, 24))
+    P.call("construct_bsp")
+    P.call("add_area_light", (-10, 20, 20), 2.0, 10.0, 2)
+    return P.g, P.o

@@ -437,3 +437,35 @@ def test_ppm_photon_shards_add_up(ctx):
     assert (acc_a[:, 0] == acc_b[:, 0]).all()                       # photon counts: exact
     assert np.allclose(acc_a[:, 1:], acc_b[:, 1:], rtol=1e-12, atol=1e-12)
     assert acc_a[:, 0].sum() > 1000
+
+
+# ---- god ray ------------------------------------------------------------------------------------------
+def test_godray_room(ctx):
+    """light-shaft photons (GeneratePhotons, GodRay.h:202-215) and the per-ray photon gather (RadianceEvaluation, :217-245)
+    inside the Whitted recursion, depth 2 (reflected rays gather photons along THEIR line)"""
+    import oracle_bind as ob
+    import ray_tracing_amd as rta
+    g, o = scenes.build_room()
+    gg = rta.GodRay(ctx, g, (155, 155, 50), seed=9)
+    og = ob.OracleGodRay(o, (155, 155, 50), seed=9)
+    for x in (gg, og):
+        x.add_area_light_source_xz(6.0, (-3.0, 0.0), (9.0, 10.0), 0.4, (1.0, -2.0, -1.0))      # Layout.h:318 with a coarser grid
+        x.add_area_light_source_xz(7.0, (2.0, 1.0), (6.0, 4.0), 0.25, (0.2, -2.0, -0.7))
+        x.photon_mapping_pass()
+    pg, po = gg.photons(), og.photons()
+    assert pg.shape == po.shape and pg.shape[0] > 20000
+    assert np.abs(pg - po).max() < 1e-9
+    cam_args = dict(scenes.ROOM_CAMERA, res=20, depth=2)
+    cam = rta.Camera(**cam_args)
+    rgb, ids = gg.render(cam, background=(5, 5, 5))
+    rgb_ref, ids_ref = og.render(scenes.oracle_camera(cam_args), background=(5, 5, 5))
+    assert (ids == ids_ref).all()
+    # the same frame without light shafts, to see what they add
+    cam.render_raytracer(ctx, g, background=(5, 5, 5))
+    plain = cam.rgb()
+    lit = (np.abs(rgb_ref - plain).max(axis=1) > 1e-9)
+    err = _rel_err(rgb, rgb_ref)
+    print("god ray: %d photons, %d of %d pixels lit by shafts (max +%.1f), max rel err %.3g" % (pg.shape[0], lit.sum(), lit.size,
+                                                                                         (rgb_ref - plain).max(), err.max()))
+    assert lit.mean() > 0.05
+    assert err.max() < 1e-3
