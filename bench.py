@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--leaf-refine", type=int, default=None, help="library leaf refinement (default: library default, 32)")
     ap.add_argument("--mode", choices=["frames", "samples"], default="frames")
     ap.add_argument("--streams", type=int, default=2, help="frames in flight per GPU (one scene handle and HIP stream each)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel events inside the timed region (no roofline object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
@@ -59,11 +60,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
+    rehearsal = args.backend != "nccl"
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())       # every rank on the GPUs that exist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearsal else dev                       # where the collectives' tensors live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(args.backend)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- scene (host: build mesh + BSP; device: upload) ----
     t0 = time.time()
@@ -178,10 +186,10 @@ def main():
     ms_one_in_flight = (time.perf_counter() - t1) * 1e3 / n_one
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        rr = torch.tensor([float(rays_per_frame)], dtype=torch.float64, device=dev)
+        rr = torch.tensor([float(rays_per_frame)], dtype=torch.float64, device=cdev)
         dist.all_reduce(rr)
         total_rays_per_step = float(rr.item())
     else:
