@@ -211,6 +211,33 @@ int rt_hip_render_focusing(rt_hip_scene *scene, const rt_hip_camera *cam, const 
 int rt_hip_render_focusing_dev(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
                                double *d_rgb, void *stream);
 
+/* ---- adaptive anti-aliasing: CCamera::Render_RayTracer_Antialiasing (Camera.h:83-169) and, with focusing != 0,
+ * CCamera::Render_Focusing_Antialiasing (Camera.h:201-280; params->spp lens samples, params->lens_radius).
+ * A pinhole pass gives the depth / normal / type (/ colour) maps; pixels where |Laplace| of a map (3x3 kernel of
+ * Camera.h:285, cv::filter2D's default reflect-101 border) exceeds its threshold are re-sampled with
+ * oversample_times rays jittered by random(r0) on the picture plane.  Zero fields take the reference's constants
+ * (Camera.h:77-82).  rgb as in rt_hip_render_whitted (final CColour values); edge_mask (optional) = 1 where the
+ * pixel was re-sampled.  Shards by pixels only (the stencil's neighbour rows are rendered as a halo).  A pixel
+ * whose primary ray hits nothing (the reference dereferences NULL there, Camera.h:109) counts with
+ * depth = Dist(inftyPt, viewPt), a zero normal and type -1. */
+typedef struct {
+  uint32_t struct_size;
+  uint32_t oversample_times;        /* 0 -> 100 */
+  double   r0;                      /* 0 -> 0.007 */
+  double   depth_grad_threshold;    /* 0 -> 0.8 */
+  double   norm_grad_threshold;     /* 0 -> 0.8 */
+  double   type_grad_threshold;     /* 0 -> 0.5 */
+  double   colour_grad_threshold;   /* 0 -> 80; not used when focusing (Camera.h:258-262) */
+  uint32_t focusing;                /* 0: Render_RayTracer_Antialiasing, 1: Render_Focusing_Antialiasing */
+  uint32_t reserved;
+} rt_hip_aa_params;
+int rt_hip_render_antialiasing(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params, const rt_hip_aa_params *aa,
+                               double *rgb, uint8_t *edge_mask);
+int rt_hip_render_antialiasing_dev(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params, const rt_hip_aa_params *aa,
+                                   double *d_rgb, uint8_t *d_edge_mask, void *stream);
+/* number of pixels the last anti-aliasing call on this scene re-sampled */
+int rt_hip_last_aa_edges(rt_hip_scene *scene, uint64_t *n);
+
 /* ---- progressive photon mapping: CPhotonMapper (PhotonMapper.h:133-376) driven as in CCamera::Render_PhotonMapper
  * (Camera.h:291-313).  begin = the eye pass (RayTracingPass per pixel, :159-220: Whitted + a hit point on every
  * diffuse surface of the ray tree); photon_num = photonNum (:155, 0 -> 50000), times = the passes that will be run
@@ -257,6 +284,7 @@ int rt_hip_godray_destroy(rt_hip_godray *g);
 #define RT_HIP_K_TRACE_OCCLUDED 6
 #define RT_HIP_K_SHADOW         7   /* luminosity of every light at every hit: occlusion walks */
 #define RT_HIP_K_ORDER          8   /* heavy-first work ordering (classification + stable partition) */
+#define RT_HIP_K_AA             9   /* anti-aliasing drivers: G-buffer maps, edge mask, per-pixel sums */
 #define RT_HIP_K_COUNT          12
 typedef struct { double ms[RT_HIP_K_COUNT]; uint64_t launches[RT_HIP_K_COUNT]; } rt_hip_profile;
 int rt_hip_set_profiling(rt_hip_scene *scene, int on);

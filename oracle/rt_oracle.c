@@ -1161,6 +1161,111 @@ void orc_render_focusing(orc_scene *s, const orc_camera *c, double radius, int s
   (void)threads;
 }
 
+/* ------------------------------------------------------------------ adaptive anti-aliasing (Camera.h:77-169, 201-289) */
+/* cv::filter2D(mat, grad, CV_64F, [0 1 0; 1 -4 1; 0 1 0]) with its default border, BORDER_REFLECT_101 (OpenCV 2.4.9 is
+ * not in the image: restated from its documentation; products accumulated in the kernel's row-major order) */
+static double laplace_at(const double *m, int W, int H, int v, int h)       /* Camera.h:282-289 */
+{
+  int vu = (v == 0) ? ((H > 1) ? 1 : 0) : v - 1, vd = (v == H - 1) ? ((H > 1) ? H - 2 : 0) : v + 1;
+  int hl = (h == 0) ? ((W > 1) ? 1 : 0) : h - 1, hr = (h == W - 1) ? ((W > 1) ? W - 2 : 0) : h + 1;
+  double s = m[(size_t)vu * W + h];
+  s += m[(size_t)v * W + hl]; s += m[(size_t)v * W + h] * -4.0; s += m[(size_t)v * W + hr]; s += m[(size_t)vd * W + h];
+  return s;
+}
+
+/* aa[6] = oversampleTimes, r0, depth / norm / type / colour thresholds (Camera.h:77-82).  focusing = 0:
+ * Render_RayTracer_Antialiasing (Camera.h:83-169); focusing = 1: Render_Focusing_Antialiasing (Camera.h:201-280) with
+ * spp lens samples of the given radius.  A primary ray that hits nothing (NULL dereference in the reference,
+ * Camera.h:109) counts with depth = Dist(inftyPt, viewPt), a zero normal and type -1.
+ * RNG keys: lens point (pixel, lens sample i, path 0, stream 0, dims 0..2); picture-plane jitter (pixel,
+ * ray index i * oversampleTimes + j, path 0, stream 1, dims 0..2); the ray tree below uses (pixel, ray index). */
+void orc_render_antialiasing(orc_scene *s, const orc_camera *c, const double aa[6], int focusing, double radius, int spp,
+                             const double bg[3], uint64_t seed, double *rgb, unsigned char *edge_mask, int threads)
+{
+  cam_t k = cam_init(c);
+  const int W = k.W, H = k.H;
+  const size_t total = (size_t)W * H;
+  const int os = (int)aa[0];
+  const double r0 = aa[1];
+  col_t bgc = C3(bg[0], bg[1], bg[2]);
+  double *maps = (double *)malloc(total * 8 * sizeof(double));
+#ifdef _OPENMP
+  int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nt)
+#endif
+  for (long long p = 0; p < (long long)total; p++) {                      /* Camera.h:98-121, 213-232 */
+    int v = (int)(p / W), h = (int)(p % W);
+    v3 cur = cam_cur_pt(&k, h, v);
+    ray_t ray = mk_ray(k.view_pt, v_unitize(v_sub(cur, k.view_pt)));
+    inter_t in = first_inter_pt(s, ray, 1);                              /* :106 */
+    v3 norm = V3(0, 0, 0); double t, type = -1;
+    if (in.obj >= 0) {
+      norm = obj_norm(&s->objs[in.obj], in.pt, in.u, in.v);              /* :109 */
+      type = (double)s->objs[in.obj].type;                                /* :115 */
+    }
+    t = v_dist(in.pt, ray.o);                                             /* :110 */
+    maps[p] = t; maps[total + p] = norm.x; maps[2 * total + p] = norm.y; maps[3 * total + p] = norm.z; maps[4 * total + p] = type;
+    if (!focusing) {
+      rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = 0; g.path = 1;
+      col_t c0 = ray_tracer(s, ray, k.depth, 1, bgc, g, NULL);           /* :116 */
+      maps[5 * total + p] = c0.r; maps[6 * total + p] = c0.g; maps[7 * total + p] = c0.b;
+    }
+  }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
+#endif
+  for (long long p = 0; p < (long long)total; p++) {                      /* Camera.h:134-165, 243-276 */
+    int v = (int)(p / W), h = (int)(p % W);
+    v3 cur = cam_cur_pt(&k, h, v);
+    int edge = fabs(laplace_at(maps, W, H, v, h)) > aa[2] ||
+               fabs(laplace_at(maps + total, W, H, v, h)) > aa[3] ||
+               fabs(laplace_at(maps + 2 * total, W, H, v, h)) > aa[3] ||
+               fabs(laplace_at(maps + 3 * total, W, H, v, h)) > aa[3] ||
+               fabs(laplace_at(maps + 4 * total, W, H, v, h)) > aa[4];
+    if (!focusing)
+      edge = edge || fabs(laplace_at(maps + 5 * total, W, H, v, h)) > aa[5] ||
+             fabs(laplace_at(maps + 6 * total, W, H, v, h)) > aa[5] ||
+             fabs(laplace_at(maps + 7 * total, W, H, v, h)) > aa[5];
+    if (edge_mask) edge_mask[p] = (unsigned char)edge;
+    col_t colour = C3(0, 0, 0);
+    const int n_lens = focusing ? spp : 1;
+    for (int i = 0; i < n_lens; i++) {
+      v3 pnt = k.view_pt;
+      if (focusing) {                                                     /* :256 */
+        rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = (uint32_t)i; g.path = 0;
+        double jx = ref_random(radius, 1000, &g, 0, 0, 0);
+        double jy = ref_random(radius, 1000, &g, 0, 0, 1);
+        double jz = ref_random(radius, 1000, &g, 0, 0, 2);
+        pnt = V3(k.view_pt.x + jx, k.view_pt.y + jy, k.view_pt.z + jz);
+      }
+      if (edge) {
+        for (int j = 0; j < os; j++) {                                    /* :152-157, 264-269 */
+          rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = (uint32_t)(i * os + j); g.path = 0;
+          double kx = ref_random(r0, 1000, &g, 1, 0, 0);
+          double ky = ref_random(r0, 1000, &g, 1, 0, 1);
+          double kz = ref_random(r0, 1000, &g, 1, 0, 2);
+          v3 cur1 = V3(cur.x + kx, cur.y + ky, cur.z + kz);
+          ray_t ray1 = mk_ray(pnt, v_unitize(v_sub(cur1, pnt)));
+          g.path = 1;
+          col_t sc = ray_tracer(s, ray1, k.depth, 1, bgc, g, NULL);
+          colour = c_add(colour, c_div(sc, focusing ? (double)(spp * os) : (double)os));
+        }
+        continue;
+      }
+      if (focusing) {                                                     /* :272 */
+        rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = (uint32_t)i; g.path = 1;
+        ray_t ray = mk_ray(pnt, v_unitize(v_sub(cur, pnt)));
+        colour = c_add(colour, c_div(ray_tracer(s, ray, k.depth, 1, bgc, g, NULL), spp));
+      } else {
+        colour = C3(maps[5 * total + p], maps[6 * total + p], maps[7 * total + p]);   /* :161-162: the same ray again */
+      }
+    }
+    rgb[3 * p] = colour.r; rgb[3 * p + 1] = colour.g; rgb[3 * p + 2] = colour.b;
+  }
+  free(maps);
+  (void)threads;
+}
+
 /* ------------------------------------------------------------------ batch queries for tests */
 
 /* ------------------------------------------------------------------ progressive photon mapping (PhotonMapper.h, Camera.h:291-313) */

@@ -104,6 +104,11 @@ void orc_render_focusing(orc_scene *s, const orc_camera *c, double radius, int s
                          uint64_t seed, double *rgb, size_t first, size_t count, int threads,
                          int64_t *counters);
 
+/* Adaptive anti-aliasing: Camera.h:83-169 (focusing = 0) and Camera.h:201-280 (focusing = 1).
+ * aa[6] = oversampleTimes, r0, depth / norm / type / colour thresholds (Camera.h:77-82). */
+void orc_render_antialiasing(orc_scene *s, const orc_camera *c, const double aa[6], int focusing, double radius, int spp,
+                             const double bg[3], uint64_t seed, double *rgb, unsigned char *edge_mask, int threads);
+
 /* Progressive photon mapping: Camera.h:291-313 Render_PhotonMapper + PhotonMapper.h.  begin = eye pass
  * (RayTracingPass per pixel, hit points on diffuse surfaces) + hit-point kd-tree; pass = one iteration of
  * PhotonMappingPass (emit photon_num photons per light [x sampleNum^2 for an area light], trace, gather, update).

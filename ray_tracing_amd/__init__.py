@@ -56,6 +56,19 @@ class Params(C.Structure):
             setattr(self, k, v)
 
 
+class AaParams(C.Structure):
+    """rt_hip_aa_params: zero fields take the reference's constants (Camera.h:77-82)"""
+    _fields_ = [("struct_size", C.c_uint32), ("oversample_times", C.c_uint32), ("r0", C.c_double),
+                ("depth_grad_threshold", C.c_double), ("norm_grad_threshold", C.c_double), ("type_grad_threshold", C.c_double),
+                ("colour_grad_threshold", C.c_double), ("focusing", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.struct_size = C.sizeof(AaParams)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "shadow_rays", "node_visits", "prim_tests", "exact_tests",
                                           "wave_node_visits", "wave_prim_tests", "reserved")]
@@ -112,6 +125,10 @@ host.rth_camera_seed.argtypes = [_vp, C.c_uint64]
 host.rth_camera_raw.argtypes = [_vp]
 host.rth_render_raytracer.argtypes = [_vp, _vp, _vp, d3]
 host.rth_render_focusing.argtypes = [_vp, _vp, _vp, C.c_double, d3, C.c_uint]
+host.rth_render_raytracer_antialiasing.argtypes = [_vp, _vp, _vp, d3, C.c_uint]
+host.rth_render_focusing_antialiasing.argtypes = [_vp, _vp, _vp, C.c_double, d3, C.c_uint, C.c_uint]
+host.rth_camera_edge_mask.argtypes = [_vp]
+host.rth_camera_edge_mask.restype = C.POINTER(C.c_uint8)
 host.rth_camera_rgb.argtypes = [_vp]
 host.rth_camera_prim_id.argtypes = [_vp]
 host.rth_camera_image.argtypes = [_vp]
@@ -127,6 +144,9 @@ hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Pa
 hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_render_focusing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp]
 hip.rt_hip_render_focusing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
+hip.rt_hip_render_antialiasing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.POINTER(AaParams), _vp, _vp]
+hip.rt_hip_render_antialiasing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.POINTER(AaParams), _vp, _vp, _vp]
+hip.rt_hip_last_aa_edges.argtypes = [_vp, C.POINTER(C.c_uint64)]
 hip.rt_hip_godray_create.argtypes = [_vp, d3, C.c_uint64, C.POINTER(_vp)]
 hip.rt_hip_godray_add_area_xz.argtypes = [_vp, C.c_double, C.c_double * 2, C.c_double * 2, C.c_double, d3]
 hip.rt_hip_godray_build.argtypes = [_vp]
@@ -449,6 +469,18 @@ class Camera:
 
     def render_focusing(self, ctx, scene, radius, background=(0, 0, 0), spp=100):
         _chk_host(host.rth_render_focusing(self._h, ctx._h, scene._h, radius, d3(*background), spp))
+
+    def render_raytracer_antialiasing(self, ctx, scene, background=(0, 0, 0), oversample_times=100):
+        """CCamera::Render_RayTracer_Antialiasing, Camera.h:83-169"""
+        _chk_host(host.rth_render_raytracer_antialiasing(self._h, ctx._h, scene._h, d3(*background), oversample_times))
+
+    def render_focusing_antialiasing(self, ctx, scene, radius, background=(0, 0, 0), spp=100, oversample_times=100):
+        """CCamera::Render_Focusing_Antialiasing, Camera.h:201-280"""
+        _chk_host(host.rth_render_focusing_antialiasing(self._h, ctx._h, scene._h, radius, d3(*background), spp, oversample_times))
+
+    def edge_mask(self):
+        p = host.rth_camera_edge_mask(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.width * self.height,)).copy()
 
     def rgb(self):
         n = self.width * self.height

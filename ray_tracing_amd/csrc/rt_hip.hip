@@ -85,6 +85,8 @@ struct rt_hip_scene {
   unsigned int last_n_level[kMaxLevels] = {0}; int last_level = 0;   // sizes of the level arrays of the last run
   bool keep_uv = false;            // photon mapping eye pass: keep the (u, v) of every node's hit (k_shade overwrites them)
   DevBuf uv[kMaxLevels];
+  DevBuf aa_maps, aa_edges;        // anti-aliasing drivers: G-buffer maps, list of masked pixels
+  uint64_t last_aa_edges = 0;
   // optional per-kernel timing (rt_hip_set_profiling)
   bool prof_on = false;
   struct EvPair { hipEvent_t a, b; int k; };
@@ -829,7 +831,7 @@ extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
   for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &b : s->levels) b.release();
   for (auto &b : s->uv) b.release();
-  s->counter.release(); s->staging.release(); s->lum.release(); s->order.release();
+  s->counter.release(); s->staging.release(); s->lum.release(); s->order.release(); s->aa_maps.release(); s->aa_edges.release();
   delete s;
   return RT_HIP_OK;
 }
@@ -1121,38 +1123,16 @@ extern "C" int rt_hip_camera_size(const rt_hip_camera *cam, int *w, int *h)
 
 static int godray_level(rt_hip_scene *s, PathNode *nodes, unsigned int n, hipStream_t st);   // rt_godray.inc
 
-// the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
-static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, double *direct_rgb = nullptr, int32_t *direct_id = nullptr)
+// Levels of the ray tree once level 0 holds its n0 nodes with their closest hits (k_primary / k_primary_list):
+// shadow pass, shading + child rays, closest hit of the children, ... and the bottom-up composition.
+// order1: optional heavy-first order of the level-0 waves for the shadow pass.
+static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, uint64_t n0, const unsigned int *order1,
+                           uint64_t primary_rays, double *direct_rgb, int32_t *direct_id)
 {
-  const uint64_t n_waves = (uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * A.n_samples;
-  const uint64_t n0 = n_waves * 64;      // level 0 in tile order, edge tiles padded
-  if (A.pixel_count == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
-  int rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
-  rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
+  int rc;
   RenderCounters *cnt = (RenderCounters *)s->counter.p;
   Stats *gs = stats ? s->ctx->d_stats : nullptr;
   const bool param = s->dev.has_param != 0;
-  const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
-  PathNode *L0 = (PathNode *)s->levels[0].p;
-  // heavy-first order of the level-0 waves (only worth it with a tree)
-  unsigned int *order0 = nullptr, *order1 = nullptr; unsigned char *flags0 = nullptr, *flags1 = nullptr;
-  if (s->dev.has_tree) {
-    rc = s->order.ensure(n_waves * 10 + 64); if (rc) return rc;
-    order0 = (unsigned int *)s->order.p; order1 = order0 + n_waves;
-    flags0 = (unsigned char *)(order1 + n_waves); flags1 = flags0 + n_waves;
-    ProfScope ps(s, RT_HIP_K_ORDER, st);
-    hipLaunchKernelGGL(k_classify, dim3((unsigned int)((n_waves + 255) / 256)), dim3(256), 0, st, s->dev, A, (unsigned int)n_waves, flags0);
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, order0);
-  }
-  {
-    ProfScope ps(s, RT_HIP_K_PRIMARY, st);
-    RT_LAUNCH_SP(k_primary, stats, param, dim3(pblocks), st, s->dev, A, L0, (const unsigned int *)order0, flags1, gs);
-  }
-  if (s->dev.has_tree && s->dev.n_lights > 0) {
-    ProfScope ps(s, RT_HIP_K_ORDER, st);
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags1, (unsigned int)n_waves, order1);
-  } else order1 = nullptr;
-  HIP_TRY(hipGetLastError());
   unsigned int n_level[rt_hip_scene::kMaxLevels] = {0};
   n_level[0] = (unsigned int)n0;
   int depth = A.cam.depth < 1 ? 1 : A.cam.depth;
@@ -1210,9 +1190,45 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   }
   for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) s->last_n_level[lv] = (lv <= last) ? n_level[lv] : 0;
   s->last_level = last;
-  uint64_t rays = A.pixel_count * A.n_samples; for (int lv = 1; lv <= last; lv++) rays += n_level[lv];
+  uint64_t rays = primary_rays; for (int lv = 1; lv <= last; lv++) rays += n_level[lv];
   s->last_rays += rays;
   return RT_HIP_OK;
+}
+
+
+// the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
+static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, double *direct_rgb = nullptr, int32_t *direct_id = nullptr)
+{
+  const uint64_t n_waves = (uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * A.n_samples;
+  const uint64_t n0 = n_waves * 64;      // level 0 in tile order, edge tiles padded
+  if (A.pixel_count == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
+  int rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
+  rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
+  RenderCounters *cnt = (RenderCounters *)s->counter.p;
+  Stats *gs = stats ? s->ctx->d_stats : nullptr;
+  const bool param = s->dev.has_param != 0;
+  const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
+  PathNode *L0 = (PathNode *)s->levels[0].p;
+  // heavy-first order of the level-0 waves (only worth it with a tree)
+  unsigned int *order0 = nullptr, *order1 = nullptr; unsigned char *flags0 = nullptr, *flags1 = nullptr;
+  if (s->dev.has_tree) {
+    rc = s->order.ensure(n_waves * 10 + 64); if (rc) return rc;
+    order0 = (unsigned int *)s->order.p; order1 = order0 + n_waves;
+    flags0 = (unsigned char *)(order1 + n_waves); flags1 = flags0 + n_waves;
+    ProfScope ps(s, RT_HIP_K_ORDER, st);
+    hipLaunchKernelGGL(k_classify, dim3((unsigned int)((n_waves + 255) / 256)), dim3(256), 0, st, s->dev, A, (unsigned int)n_waves, flags0);
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, order0);
+  }
+  {
+    ProfScope ps(s, RT_HIP_K_PRIMARY, st);
+    RT_LAUNCH_SP(k_primary, stats, param, dim3(pblocks), st, s->dev, A, L0, (const unsigned int *)order0, flags1, gs);
+  }
+  if (s->dev.has_tree && s->dev.n_lights > 0) {
+    ProfScope ps(s, RT_HIP_K_ORDER, st);
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags1, (unsigned int)n_waves, order1);
+  } else order1 = nullptr;
+  HIP_TRY(hipGetLastError());
+  return run_levels_from(s, A, stats, st, n0, order1, A.pixel_count * A.n_samples, direct_rgb, direct_id);
 }
 
 static int fill_args(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, RenderArgs *A)
@@ -1254,6 +1270,24 @@ extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *c
   return RT_HIP_OK;
 }
 
+// Camera.h:187-192 for the sample shard [s_first, s_first + s_count) of spp: sum of sample / spp into d_rgb
+static int focusing_batches(rt_hip_scene *s, RenderArgs A, bool stats, uint32_t spp, uint32_t s_first, uint32_t s_count, double *d_rgb, hipStream_t st)
+{
+  int rc;
+  // batch the samples so that one level-0 array stays near 1 GiB
+  uint64_t per = (1ull << 30) / ((uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * 64 * sizeof(PathNode));
+  uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per, 64));
+  for (uint32_t done = 0; done < s_count; done += batch) {
+    A.sample_first = s_first + done; A.n_samples = std::min(batch, s_count - done);
+    rc = run_levels(s, A, stats, st); if (rc) return rc;
+    { ProfScope ps(s, RT_HIP_K_RESOLVE, st);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, (double)spp,
+                       done ? 1 : 0, d_rgb, (int32_t *)nullptr); }
+    HIP_TRY(hipGetLastError());
+  }
+  return RT_HIP_OK;
+}
+
 extern "C" int rt_hip_render_focusing_dev(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *d_rgb, void *stream)
 {
   RenderArgs A; int rc = fill_args(s, cam, P, &A); if (rc) return rc;
@@ -1267,18 +1301,7 @@ extern "C" int rt_hip_render_focusing_dev(rt_hip_scene *s, const rt_hip_camera *
   rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
   s->last_rays = 0; s->last_shadow = 0;
-  // batch the samples so that one level-0 array stays near 1 GiB
-  uint64_t per = (1ull << 30) / ((uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * 64 * sizeof(PathNode));
-  uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per, 64));
-  for (uint32_t done = 0; done < s_count; done += batch) {
-    A.sample_first = s_first + done; A.n_samples = std::min(batch, s_count - done);
-    rc = run_levels(s, A, P->collect_stats != 0, st); if (rc) return rc;
-    { ProfScope ps(s, RT_HIP_K_RESOLVE, st);
-    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, (double)spp,
-                       done ? 1 : 0, d_rgb, (int32_t *)nullptr); }
-    HIP_TRY(hipGetLastError());
-  }
-  return RT_HIP_OK;
+  return focusing_batches(s, A, P->collect_stats != 0, spp, s_first, s_count, d_rgb, st);
 }
 
 static int render_host(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *rgb, int32_t *prim_id, bool focusing)
@@ -1315,5 +1338,6 @@ extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *
   return RT_HIP_OK;
 }
 
+#include "rt_aa.inc"
 #include "rt_ppm.inc"
 #include "rt_godray.inc"

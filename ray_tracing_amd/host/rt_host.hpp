@@ -423,6 +423,27 @@ class Camera {                   // CCamera, Camera.h:14-51
     for (double &c : rgb_) c = std::min(255.0, c);        // the running clamp of Colour.h:41-47, applied once
     to_picture();
   }
+  // Render_RayTracer_Antialiasing, Camera.h:83-169: G-buffer pass, Laplacian edge mask, oversampleTimes jittered rays
+  // on the masked pixels.  edge_mask(): 1 where a pixel was re-sampled.
+  void Render_RayTracer_Antialiasing(Context &ctx, Scene &scene, Colour background = Colour(0, 0, 0), uint32_t oversampleTimes = 100)
+  {
+    rt_hip_params p = params(background);
+    rt_hip_aa_params a{}; a.struct_size = sizeof a; a.oversample_times = oversampleTimes;
+    rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.clear(); mask_.assign((size_t)w_ * h_, 0);
+    check(rt_hip_render_antialiasing(scene.Device(ctx), &cam_, &p, &a, rgb_.data(), mask_.data()), "rt_hip_render_antialiasing");
+    to_picture();
+  }
+  // Render_Focusing_Antialiasing, Camera.h:201-280: spp lens samples per pixel, x oversampleTimes on the masked pixels
+  void Render_Focusing_Antialiasing(Context &ctx, Scene &scene, double radius, Colour background = Colour(0, 0, 0), uint32_t spp = 100,
+                                    uint32_t oversampleTimes = 100)
+  {
+    rt_hip_params p = params(background);
+    p.spp = spp; p.lens_radius = radius;
+    rt_hip_aa_params a{}; a.struct_size = sizeof a; a.oversample_times = oversampleTimes; a.focusing = 1;
+    rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.clear(); mask_.assign((size_t)w_ * h_, 0);
+    check(rt_hip_render_antialiasing(scene.Device(ctx), &cam_, &p, &a, rgb_.data(), mask_.data()), "rt_hip_render_antialiasing");
+    to_picture();
+  }
   // Render_PhotonMapper, Camera.h:291-313: eye pass, then `times` photon passes of photonNum photons per light
   // (PhotonMapper.h:155: 50000); the picture is the reference's CV_8UC3 image
   void Render_PhotonMapper(Context &ctx, Scene &scene, int times, Colour background = Colour(0, 0, 0), uint32_t photonNum = 50000)
@@ -450,6 +471,7 @@ class Camera {                   // CCamera, Camera.h:14-51
   const std::vector<double> &rgb() const { return rgb_; }
   const std::vector<int32_t> &prim_id() const { return prim_; }
   const std::vector<uint8_t> &image() const { return picture_; }
+  const std::vector<uint8_t> &edge_mask() const { return mask_; }
   // binary PPM instead of cv::imwrite (Camera.h:73)
   void WritePPM(const std::string &path) const
   {
@@ -474,7 +496,7 @@ class Camera {                   // CCamera, Camera.h:14-51
     }
   }
   rt_hip_camera cam_{}; int w_ = 0, h_ = 0;
-  std::vector<double> rgb_; std::vector<int32_t> prim_; std::vector<uint8_t> picture_;
+  std::vector<double> rgb_; std::vector<int32_t> prim_; std::vector<uint8_t> picture_, mask_;
 };
 
 }}  // namespace rt::host

@@ -68,6 +68,22 @@ def render_whitted_rows(rta, ctx, scene, camera, background=(0, 0, 0), stream=No
     return gather_rows(local, camera.height, camera.width, 3, group)
 
 
+def render_antialiasing_rows(rta, ctx, scene, camera, aa=None, background=(0, 0, 0), seed=0, spp=0, lens_radius=0.0, stream=None, group=None):
+    """Render_RayTracer_Antialiasing / Render_Focusing_Antialiasing split by rows: the edge mask needs the rows next
+    to a block, which the ABI renders as a halo, so the blocks again equal the single-GPU frame"""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    first, count = row_shard(camera.height, camera.width, rank, world)
+    local = torch.empty((count, 3), dtype=torch.float64, device="cuda")
+    if count:
+        p = rta.Params(background=background, seed=seed, spp=spp, lens_radius=lens_radius, pixel_first=first, pixel_count=count)
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rta.check(rta.hip.rt_hip_render_antialiasing_dev(scene.device(ctx), camera.raw, p, aa if aa is not None else rta.AaParams(),
+                                                         C.c_void_p(local.data_ptr()), None, C.c_void_p(s.cuda_stream)))
+    return gather_rows(local, camera.height, camera.width, 3, group)
+
+
 def render_focusing_samples(rta, ctx, scene, camera, radius, spp, background=(0, 0, 0), seed=0, stream=None, group=None):
     """Render_Focusing split by samples over the ranks of `group`; returns the clamped frame (H*W, 3) f64"""
     import torch

@@ -44,6 +44,7 @@ L.orc_trace_closest.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp, _vp
 L.orc_camera_size.argtypes = [C.POINTER(OrcCamera), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 L.orc_camera_rays.argtypes = [C.POINTER(OrcCamera), _vp]
 L.orc_render_whitted.argtypes = [_vp, C.POINTER(OrcCamera), d3, C.c_uint64, _vp, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]
+L.orc_render_antialiasing.argtypes = [_vp, C.POINTER(OrcCamera), C.c_double * 6, C.c_int, C.c_double, C.c_int, d3, C.c_uint64, _vp, _vp, C.c_int]
 L.orc_render_focusing.argtypes = [_vp, C.POINTER(OrcCamera), C.c_double, C.c_int, d3, C.c_uint64, _vp, C.c_size_t, C.c_size_t, C.c_int, _vp]
 L.orc_godray_new.argtypes = [_vp, d3, C.c_uint64]
 L.orc_godray_new.restype = _vp
@@ -176,6 +177,18 @@ class OracleScene:
         rgb = np.zeros((n, 3))
         L.orc_render_focusing(self.h, C.byref(cam), radius, spp, d3(*background), seed, rgb.ctypes.data, first, count, threads, None)
         return rgb
+
+    def render_antialiasing(self, cam, focusing=False, radius=0.0, spp=100, oversample_times=100, r0=0.007,
+                            thresholds=(0.8, 0.8, 0.5, 80.0), background=(0, 0, 0), seed=0, threads=0):
+        """Camera.h:83-169 / 201-280; returns (rgb (n,3), edge mask (n,) uint8)"""
+        w, h = C.c_int(), C.c_int()
+        L.orc_camera_size(C.byref(cam), C.byref(w), C.byref(h))
+        n = w.value * h.value
+        rgb = np.zeros((n, 3)); mask = np.zeros(n, dtype=np.uint8)
+        aa = (C.c_double * 6)(float(oversample_times), r0, *thresholds)
+        L.orc_render_antialiasing(self.h, C.byref(cam), aa, int(bool(focusing)), radius, spp, d3(*background), seed,
+                                  rgb.ctypes.data, mask.ctypes.data, threads)
+        return rgb, mask
 
     def camera_rays(self, cam):
         w, h = C.c_int(), C.c_int()

@@ -43,14 +43,15 @@ class _Pair:
 
 
 def build_icosahedron(material="plastic", light="point_area", gpu=True, oracle=True, bsp=True, leaf_refine=None,
-                      extra_sphere=False):
+                      extra_sphere=False, planes=True):
     """C1: Layout3_Icosahedron (Layout.h:136-160) without textures.
     light: 'point_area' = AddAreaLight((-10,20,20),1,0,1) (deterministic), 'area10' = Layout.h:155,
            'point' / 'parallel' use the brute-force shadow rules of Light.h."""
     P = _Pair(0.5, gpu, oracle)
     plastic = P.mat("plastic")
-    P.call("add_plane", (0, 0, 0), (0, 0, 1), mat=plastic, colour=(255, 255, 255))
-    P.call("add_plane", (10, 0, 0), (-1, 0, 0), mat=plastic, colour=(0, 0, 0))
+    if planes:      # planes=False: primary rays can leave the scene
+        P.call("add_plane", (0, 0, 0), (0, 0, 1), mat=plastic, colour=(255, 255, 255))
+        P.call("add_plane", (10, 0, 0), (-1, 0, 0), mat=plastic, colour=(0, 0, 0))
     P.call("read_obj_triangle", ICOSA_OBJ, (0, -1, 0), 0.0015, mat=P.mat(material), colour=(241, 46, 24))
     if extra_sphere:
         P.call("add_sphere", (0.3, 0.6, 0.5), 0.5, mat=P.mat("glass"), colour=(161, 143, 81))

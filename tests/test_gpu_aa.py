@@ -1,0 +1,105 @@
+"""Adaptive anti-aliasing drivers (Camera.h:83-169, 201-280) through the C ABI against the oracle.
+Tolerances: edge masks identical except where a Laplacian lies within rounding of its threshold (fraction
+<= 1e-3, reported); colours within 1e-3 relative on the pixels whose masks agree."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_err(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def _compare(cam, rgb_ref, mask_ref, what, min_edges):
+    rgb, mask = cam.rgb(), cam.edge_mask()
+    agree = mask == mask_ref
+    print("%s: %d masked pixels of %d (oracle %d), mask mismatches %d" % (what, int(mask.sum()), mask.size, int(mask_ref.sum()), int((~agree).sum())))
+    assert mask_ref.sum() >= min_edges and (mask_ref == 0).sum() >= min_edges      # both branches are exercised
+    assert (~agree).mean() <= 1e-3
+    err = _rel_err(rgb, rgb_ref)[agree]
+    print("%s: max rel err %.3g" % (what, err.max()))
+    assert err.max() < 1e-3
+
+
+@pytest.mark.parametrize("material,light,depth", [("metal", "point_area", 2), ("plastic", "area3", 1)])
+def test_raytracer_antialiasing_parity(ctx, material, light, depth):
+    import ray_tracing_amd as rta
+    g, o = scenes.build_icosahedron(material=material, light=light, extra_sphere=True)
+    cam_args = dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=40, depth=depth)
+    cam = rta.Camera(**cam_args)
+    cam.set_seed(21)
+    cam.render_raytracer_antialiasing(ctx, g, background=(200, 200, 200), oversample_times=12)
+    rgb_ref, mask_ref = o.render_antialiasing(scenes.oracle_camera(cam_args), oversample_times=12, background=(200, 200, 200), seed=21)
+    _compare(cam, rgb_ref, mask_ref, "aa %s/%s" % (material, light), 200)
+    # unmasked pixels are the plain Render_RayTracer frame
+    plain = rta.Camera(**cam_args)
+    plain.set_seed(21)
+    plain.render_raytracer(ctx, g, background=(200, 200, 200))
+    keep = cam.edge_mask() == 0
+    assert (cam.rgb()[keep] == plain.rgb()[keep]).all()
+
+
+def test_focusing_antialiasing_parity(ctx):
+    import ray_tracing_amd as rta
+    g, o = scenes.build_icosahedron(material="plastic", light="point_area", extra_sphere=True)
+    cam_args = dict(scenes.C1_CAMERA, hor=1.6, ver=1.2, res=40, depth=1)
+    cam = rta.Camera(**cam_args)
+    cam.set_seed(9)
+    cam.render_focusing_antialiasing(ctx, g, 0.1, background=(200, 200, 200), spp=5, oversample_times=6)
+    rgb_ref, mask_ref = o.render_antialiasing(scenes.oracle_camera(cam_args), focusing=True, radius=0.1, spp=5, oversample_times=6,
+                                              background=(200, 200, 200), seed=9)
+    _compare(cam, rgb_ref, mask_ref, "focusing aa", 100)
+
+
+def test_antialiasing_background_pixels(ctx):
+    """primary rays that leave the scene: depth = Dist(inftyPt, viewPt), zero normal, type -1 (documented
+    stand-in for the reference's NULL dereference) -- silhouettes against the background are edges"""
+    import ray_tracing_amd as rta
+    g, o = scenes.build_icosahedron(material="plastic", light="point", planes=False)
+    cam_args = dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=30, depth=1)
+    cam = rta.Camera(**cam_args)
+    cam.render_raytracer_antialiasing(ctx, g, background=(10, 20, 30), oversample_times=8)
+    rgb_ref, mask_ref = o.render_antialiasing(scenes.oracle_camera(cam_args), oversample_times=8, background=(10, 20, 30))
+    _compare(cam, rgb_ref, mask_ref, "aa with background", 50)
+
+
+def test_antialiasing_parametric_scene(ctx):
+    """Bezier patch in front of a wall (C4 geometry): the normal maps need the (u, v) of the primary hits"""
+    import ray_tracing_amd as rta
+    g, o = scenes.build_paper()
+    cam_args = dict(scenes.C4_CAMERA, hor=3.0, ver=1.7, res=24, depth=2)
+    cam = rta.Camera(**cam_args)
+    cam.set_seed(3)
+    cam.render_raytracer_antialiasing(ctx, g, oversample_times=6)
+    rgb_ref, mask_ref = o.render_antialiasing(scenes.oracle_camera(cam_args), oversample_times=6, seed=3)
+    _compare(cam, rgb_ref, mask_ref, "aa paper", 20)
+
+
+def test_antialiasing_pixel_shards_reassemble(ctx):
+    """row blocks rendered separately (with the halo rows the stencil needs) are bit-identical to the full frame"""
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(material="metal", light="point_area", extra_sphere=True)
+    cam = rta.Camera(**dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=40, depth=2))
+    n, W = cam.width * cam.height, cam.width
+    aa = rta.AaParams(oversample_times=5)
+    full = np.zeros((n, 3)); fmask = np.zeros(n, dtype=np.uint8)
+    p = rta.Params(background=(200, 200, 200), seed=4)
+    rta.check(rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, p, aa, full.ctypes.data, fmask.ctypes.data))
+    edges = rta.C.c_uint64()
+    rta.check(rta.hip.rt_hip_last_aa_edges(g.device(ctx), rta.C.byref(edges)))
+    assert edges.value == fmask.sum() > 0
+    parts, masks = [], []
+    cuts = [0, 8 * W, 40 * W + 17, n]        # whole rows and a cut inside a row
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        q = rta.Params(background=(200, 200, 200), seed=4, pixel_first=a, pixel_count=b - a)
+        out = np.zeros((b - a, 3)); m = np.zeros(b - a, dtype=np.uint8)
+        rta.check(rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, q, aa, out.ctypes.data, m.ctypes.data))
+        parts.append(out); masks.append(m)
+    assert (np.concatenate(masks) == fmask).all()
+    assert (np.concatenate(parts) == full).all()
+    # sample shards are refused
+    bad = rta.Params(sample_first=0, sample_count=1)
+    assert rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, bad, aa, full.ctypes.data, None) == -4
