@@ -86,6 +86,10 @@ typedef struct { double reflW, refrW, RI, diff, spec, shiness, emissive, ambient
  * already unitized direction of a parallel light (Light.h:77). */
 typedef struct { int32_t type; int32_t sample_num; double pos_or_dir[3]; double luminosity; double len; } rt_hip_light;
 
+/* A texture or bump texture (cv::Mat CV_8UC3 as cv::imread returns it, Object.h:198-210):
+ * bgr[(row * cols + col) * 3 + {0,1,2}] = B, G, R.  The library copies the pixels. */
+typedef struct { uint32_t rows; uint32_t cols; const uint8_t *bgr; } rt_hip_texture;
+
 /* Flattened BSPNode (BSPTree.h:20-38), 64 B.  split_axis = -1 for a leaf (then a = first index
  * into refs[], b = number of refs), else 0/1/2 (then a = left child, b = right child). */
 typedef struct {
@@ -114,6 +118,14 @@ typedef struct {
   uint32_t n_root_objects; const uint32_t *root_objects; /* bspTree.root->objects after the build (BSPTree.h:104-105) */
   uint32_t n_beziers;     const rt_hip_bezier     *beziers;
   uint32_t n_rotationals; const rt_hip_rotational *rotationals;
+  /* textures and bump textures (Object.h:69-74; colour(): :186-196, Norm(): :79-92).  n_textures == 0: none.
+   * Texel indices that the reference lets run out of the image (row == rows at a sphere's pole) are clamped
+   * into it; the column of a hit on a surface of revolution, whose angle is any real number, wraps around. */
+  uint32_t n_textures;    const rt_hip_texture *textures;
+  const int32_t *obj_texture;        /* [n_objects] index into textures, -1 = haveTexture false */
+  const int32_t *obj_bump_texture;   /* [n_objects] index into textures, -1 = haveBumpTexture false */
+  const double  *obj_texture_scale;  /* [n_objects][2] CInftyPlane textureScale, bumpTextureScale (Object.h:704-705); other types ignore it */
+  const double  *tri_texture_coord;  /* [n_triangles][3][2] CTriangle::textureCoord (Object.h:342), or NULL */
 } rt_hip_scene_desc;
 
 /* CCamera constructor arguments (Camera.h:17-18) */

@@ -124,6 +124,8 @@ void orc_material_preset(int name, double o[8])                                 
 }
 
 /* ------------------------------------------------------------------ objects (Object.h) */
+typedef struct tex_s { int rows, cols; unsigned char *bgr; } tex_t;   /* cv::Mat CV_8UC3 */
+
 typedef struct {
   int type;                 /* m_type */
   mat_t mat;
@@ -138,6 +140,10 @@ typedef struct {
   v3 ctrl[4][4]; v3 center;
   /* rotational (Object.h:800-808) */
   v2 prof[8]; int n_prof; int u_sample_num; double u_range;
+  /* textures (Object.h:69-74, 342, 704-705) */
+  const struct tex_s *texture, *bump_texture;   /* NULL = haveTexture / haveBumpTexture false */
+  double texture_scale, bump_texture_scale;
+  v2 tex_coord[3];
 } obj_t;
 
 typedef struct { int type; v3 pos_or_dir; double lum; double len; int sample_num; double lum_per_sample; } light_t;
@@ -155,6 +161,7 @@ struct orc_scene {                         /* CScene, Scene.h:12-60 */
   double ambient;
   bsp_node *root;
   int max_obj_num, max_depth;
+  tex_t **tex; int n_tex;                  /* images shared between objects (cv::Mat *, Scene.h:243) */
 };
 
 typedef struct { int64_t rays, nodes, prims, shadow; } counters_t;
@@ -202,6 +209,8 @@ static void free_node(bsp_node *n)
 void orc_scene_free(orc_scene *s)
 {
   if (!s) return;
+  for (int i = 0; i < s->n_tex; i++) { free(s->tex[i]->bgr); free(s->tex[i]); }
+  free(s->tex);
   free_node(s->root); free(s->objs); free(s->lights); free(s);
 }
 static obj_t *new_obj(orc_scene *s, int type, const double mat[8], const double col[3])
@@ -638,8 +647,135 @@ static v3 obj_initial_norm(const obj_t *o, v3 pt, double u, double v)
     default: return infty_pt();
   }
 }
-/* CBaseObject::Norm without bump texture, Object.h:79-83 */
-static v3 obj_norm(const obj_t *o, v3 pt, double u, double v) { return obj_initial_norm(o, pt, u, v); }
+/* ---- textures (Object.h:79-92, 186-196 and the per-type UV_colour / UV_norm / Tangent / Bitangent) ----
+ * texture->at<cv::Vec3b>(row, col): cv::Mat::at does not check bounds, and the reference's indices do leave the image
+ * (row == rows at a sphere's pole since PI is 3.1415926535): clamped here.  On a surface of revolution the angle of a
+ * hit is whatever real number Newton's iteration ended on (negative, beyond 2 PI): its column wraps around instead. */
+static const unsigned char *texel_at(const tex_t *t, int row, int col)
+{
+  row = row < 0 ? 0 : (row >= t->rows ? t->rows - 1 : row);
+  col = col < 0 ? 0 : (col >= t->cols ? t->cols - 1 : col);
+  return t->bgr + ((size_t)row * t->cols + col) * 3;
+}
+static int to_int(double x)          /* int(double), defined for every input */
+{
+  if (!(x > -2147483648.0)) return -2147483647 - 1;
+  if (!(x < 2147483647.0)) return 2147483647;
+  return (int)x;
+}
+static v3 plane_u0(v3 n)                                                                  /* Object.h:727-734 */
+{
+  v3 a = V3(1, 0, 0), b = V3(0, 1, 0), c = V3(0, 0, 1);
+  if (fabs(v_dot(a, n)) < 0.5) return v_unitize(v_sub(a, v_mul(n, v_dot(a, n))));
+  if (fabs(v_dot(b, n)) < 0.5) return v_unitize(v_sub(b, v_mul(n, v_dot(b, n))));
+  return v_unitize(v_sub(c, v_mul(n, v_dot(c, n))));
+}
+static v2 tri_uv(const obj_t *o, v3 pt)                                                   /* Object.h:470-486 */
+{
+  double S0 = v_len(v_cross(v_sub(o->vtx[1], pt), v_sub(o->vtx[2], pt)));
+  double S1 = v_len(v_cross(v_sub(o->vtx[0], pt), v_sub(o->vtx[2], pt)));
+  double S2 = v_len(v_cross(v_sub(o->vtx[0], pt), v_sub(o->vtx[1], pt)));
+  double S = v_len(v_cross(v_sub(o->vtx[1], o->vtx[0]), v_sub(o->vtx[2], o->vtx[0])));
+  return p2_add(p2_add(p2_mul(o->tex_coord[0], S0 / S), p2_mul(o->tex_coord[1], S1 / S)), p2_mul(o->tex_coord[2], S2 / S));
+}
+static v2 sphere_uv(const obj_t *o, v3 pt)                                                /* Object.h:289-296 */
+{
+  v2 r = {0, 0};
+  if (pt.x == 0 && pt.y == 0) return r;
+  v3 q = v_sub(pt, o->c);
+  r.v = (atan2(q.y, q.x) + PI_REF) / (2 * PI_REF);
+  r.u = (asin(q.z / o->r) + PI_REF / 2) / PI_REF;
+  return r;
+}
+static col_t obj_colour(const obj_t *o, v3 pt, double hu, double hv)                      /* Object.h:186-196 */
+{
+  if (!o->texture) return o->colour;
+  const tex_t *T = o->texture;
+  v2 uv = {0, 0};                                                                         /* Object.h:61 */
+  switch (o->type) {
+    case ORC_SPHERE: { v2 n = sphere_uv(o, pt); uv.u = to_int(n.u * T->rows); uv.v = to_int(n.v * T->cols); } break;   /* :280-287 */
+    case ORC_TRIANGLE: uv = tri_uv(o, pt); break;
+    case ORC_INFTY_PLANE: {                                                               /* :725-742 */
+      v3 u0 = plane_u0(o->n), v0 = v_cross(o->n, u0), rel = v_sub(pt, o->p0);
+      int up = to_int(v_dot(rel, u0) * o->texture_scale) % T->rows, vp = to_int(v_dot(rel, v0) * o->texture_scale) % T->cols;
+      up = (up + T->rows) % T->rows; vp = (vp + T->cols) % T->cols;
+      uv.u = up; uv.v = vp;
+    } break;
+    case ORC_ROTATIONAL: {                                                                /* :810; theta is any real: the column wraps */
+      int vc = to_int(hv * T->cols / (2 * PI_REF)) % T->cols;
+      uv.u = to_int(hu * T->rows); uv.v = (vc + T->cols) % T->cols;
+    } break;
+    case ORC_BEZIER: uv.u = to_int(hu * T->rows); uv.v = to_int(hv * T->cols); break;                  /* :1051 */
+    default: break;
+  }
+  const unsigned char *c = texel_at(T, to_int(uv.u), to_int(uv.v));                       /* :193 */
+  return C3(c[2], c[1], c[0]);                                                            /* :194 */
+}
+/* CBaseObject::Norm, Object.h:79-92 */
+static v3 obj_norm(const obj_t *o, v3 pt, double u, double v)
+{
+  v3 N = obj_initial_norm(o, pt, u, v);
+  if (!o->bump_texture) return N;
+  const tex_t *T = o->bump_texture;
+  v2 uv = {0, 0}; v3 tan = V3(0, 0, 0), bit = V3(0, 0, 0);                                /* Object.h:62-64 */
+  switch (o->type) {
+    case ORC_SPHERE: {                                                                    /* :289-319 */
+      uv = sphere_uv(o, pt);
+      double uu = uv.u, vv = uv.v, r = o->r;
+      tan = v_unitize(V3(-2 * PI_REF * r * sin(2 * PI_REF * vv - PI_REF) * cos(PI_REF * uu - PI_REF / 2), 2 * PI_REF * r * cos(2 * PI_REF * vv - PI_REF) * cos(PI_REF * uu - PI_REF / 2), 0));
+      bit = v_unitize(V3(-PI_REF * r * cos(2 * PI_REF * vv - PI_REF) * sin(PI_REF * uu - PI_REF / 2), -PI_REF * r * sin(2 * PI_REF * vv - PI_REF) * sin(PI_REF * uu - PI_REF / 2),
+                         PI_REF * r * cos(PI_REF * uu - PI_REF / 2)));
+    } break;
+    case ORC_TRIANGLE: uv = tri_uv(o, pt); break;                                         /* :479-486 */
+    case ORC_INFTY_PLANE: {                                                               /* :744-771, 700 */
+      v3 u0 = plane_u0(o->n), v0 = v_cross(o->n, u0), rel = v_sub(pt, o->p0);
+      double a = v_dot(rel, u0) / o->bump_texture_scale, b = v_dot(rel, v0) / o->bump_texture_scale;
+      uv.u = a - floor(a); uv.v = b - floor(b);
+      tan = u0; bit = v_cross(o->n, u0);
+    } break;
+    case ORC_ROTATIONAL:                                                                  /* :811-813 */
+      uv.u = u; uv.v = v / (2 * PI_REF); uv.v = uv.v - floor(uv.v);                        /* theta is any real: one turn = one image width */
+      tan = v_unitize(rot_ds_dth(o, u, v)); bit = v_unitize(rot_ds_dt(o, u, v));
+      break;
+    case ORC_BEZIER:                                                                      /* :1052-1054 */
+      uv.u = u; uv.v = v;
+      tan = v_unitize(surf_du(o, u, v)); bit = v_unitize(surf_dv(o, u, v));
+      break;
+    default: break;
+  }
+  const unsigned char *c = texel_at(T, to_int(uv.u * T->rows), to_int(uv.v * T->cols));   /* :87 */
+  return v_unitize(v_add(v_add(v_mul(bit, c[2] / 127.5 - 1), v_mul(tan, c[1] / 127.5 - 1)), v_mul(N, c[0] / 127.5 - 1)));   /* :88-90 */
+}
+
+/* registering images and attaching them (Object.h:198-210, 773-787; Scene.h:243) */
+int orc_add_texture_image(orc_scene *s, int rows, int cols, const unsigned char *bgr)
+{
+  if (rows <= 0 || cols <= 0 || !bgr) return -1;
+  tex_t *t = (tex_t *)malloc(sizeof *t);
+  t->rows = rows; t->cols = cols; t->bgr = (unsigned char *)malloc((size_t)rows * cols * 3);
+  memcpy(t->bgr, bgr, (size_t)rows * cols * 3);
+  s->tex = (tex_t **)realloc(s->tex, (size_t)(s->n_tex + 1) * sizeof *s->tex);
+  s->tex[s->n_tex] = t;
+  return s->n_tex++;
+}
+int orc_obj_add_texture(orc_scene *s, int obj, int tex, double scale)
+{
+  if (obj < 0 || obj >= s->n_objs || tex < 0 || tex >= s->n_tex) return -1;
+  s->objs[obj].texture = s->tex[tex]; s->objs[obj].texture_scale = scale;
+  return 0;
+}
+int orc_obj_add_bump_texture(orc_scene *s, int obj, int tex, double scale)
+{
+  if (obj < 0 || obj >= s->n_objs || tex < 0 || tex >= s->n_tex) return -1;
+  s->objs[obj].bump_texture = s->tex[tex]; s->objs[obj].bump_texture_scale = scale;
+  return 0;
+}
+int orc_triangle_set_tex_coord(orc_scene *s, int obj, const double tc[6])
+{
+  if (obj < 0 || obj >= s->n_objs || s->objs[obj].type != ORC_TRIANGLE) return -1;
+  for (int i = 0; i < 3; i++) { s->objs[obj].tex_coord[i].u = tc[2 * i]; s->objs[obj].tex_coord[i].v = tc[2 * i + 1]; }
+  return 0;
+}
 
 static ray_t obj_reflect_ray(const obj_t *o, ray_t ray, v3 pt, double u, double v)        /* Object.h:94-101 */
 {
@@ -817,6 +953,50 @@ void orc_tree_stats(const orc_scene *s, int64_t st[8], double root_box[6])
   }
 }
 
+/* CScene::RotationalSurfaceToMesh (Scene.h:168-213) and, with a texture, RotationalSurfaceToMesh_Texture (:215-266) */
+int orc_rotational_surface_to_mesh(orc_scene *s, const double *prof, int n_prof, int u_num, int v_num, int tex,
+                                   const double center[3], const double mat[8], const double col[3])
+{
+  if (n_prof < 2 || n_prof > 8 || u_num < 1 || v_num < 1 || tex >= s->n_tex) return -1;
+  obj_t surf; memset(&surf, 0, sizeof surf);
+  surf.n_prof = n_prof;
+  for (int i = 0; i < n_prof; i++) { surf.prof[i].u = prof[2 * i]; surf.prof[i].v = prof[2 * i + 1]; }
+  const v3 c = V3(center[0], center[1], center[2]);
+  const double du = 1 / (double)u_num, dv = 2 * PI_REF / (double)v_num;
+  const double rows = tex >= 0 ? s->tex[tex]->rows : 0, cols = tex >= 0 ? s->tex[tex]->cols : 0;
+  size_t cap = (size_t)(u_num + 3) * (size_t)(v_num + 3), n_pts = 0;
+  v3 *points = (v3 *)malloc(cap * sizeof(v3)), *normals = (v3 *)malloc(cap * sizeof(v3));
+  long pt_id = 0; int added = 0;
+  for (double u = 0, i = 0; u < 1 + EPS; u += du, i++) {
+    if (tex < 0 && fabs(u - 1) < 100 * EPS) u = 1;                                        /* :177-178 */
+    for (double v = 0, j = 0; v < 2 * PI_REF + EPS; v += dv, j++) {
+      if (tex < 0 && fabs(v - 2 * PI_REF) < 100 * EPS) v = 2 * PI_REF;                    /* :181-182 */
+      if (n_pts == cap) { cap *= 2; points = (v3 *)realloc(points, cap * sizeof(v3)); normals = (v3 *)realloc(normals, cap * sizeof(v3)); }
+      points[n_pts] = rot_point(&surf, u, v); normals[n_pts] = rot_norm(&surf, u, v); n_pts++;
+      if (i != 0 && j != 0 && pt_id - v_num - 2 >= 0) {
+        const long a = pt_id, b = pt_id - 1, cc = pt_id - v_num - 1, d = pt_id - v_num - 2;
+        const long idx[2][3] = {{a, b, cc}, {b, d, cc}};
+        const double tc[2][6] = {
+          {u * rows, v * cols / (2 * PI_REF), u * rows, (v - dv) * cols / (2 * PI_REF), (u - du) * rows, v * cols / (2 * PI_REF)},
+          {u * rows, (v - dv) * cols / (2 * PI_REF), (u - du) * rows, (v - dv) * cols / (2 * PI_REF), (u - du) * rows, v * cols / (2 * PI_REF)}};
+        for (int k = 0; k < 2; k++) {
+          double vv[9], vn[9];
+          for (int m = 0; m < 3; m++) {
+            v3 q = v_add(points[idx[k][m]], c), nq = normals[idx[k][m]];
+            vv[3 * m] = q.x; vv[3 * m + 1] = q.y; vv[3 * m + 2] = q.z; vn[3 * m] = nq.x; vn[3 * m + 1] = nq.y; vn[3 * m + 2] = nq.z;
+          }
+          int id = orc_add_triangle(s, vv, vn, mat, col);
+          if (tex >= 0) { orc_triangle_set_tex_coord(s, id, tc[k]); orc_obj_add_texture(s, id, tex, 1); }
+          added++;
+        }
+      }
+      pt_id++;
+    }
+  }
+  free(points); free(normals);
+  return added;
+}
+
 /* ------------------------------------------------------------------ closest hit (Scene.h:62-91, 319-432) */
 typedef struct { v3 pt; int obj; double u, v; } inter_t;     /* CIntersection, Scene.h:23-28 */
 static inline inter_t no_inter(void) { inter_t r; r.pt = infty_pt(); r.obj = -1; r.u = r.v = INFTY; return r; }
@@ -954,7 +1134,7 @@ static col_t local_illumination(orc_scene *s, ray_t ray, inter_t in, const rng_c
   col_t colour = C3(0, 0, 0);
   v3 norm = obj_norm(o, in.pt, in.u, in.v);
   if (v_dot(ray.d, norm) > EPS) norm = v_neg(norm);
-  col_t obj_colour = o->colour;                                          /* Object.h:186-189, untextured */
+  col_t obj_colour_ = obj_colour(o, in.pt, in.u, in.v);                  /* Scene.h:101 */
   for (int li = 0; li < s->n_lights; li++) {
     const light_t *l = &s->lights[li];
     double L = light_luminosity(s, l, li, in.pt, g);
@@ -963,7 +1143,7 @@ static col_t local_illumination(orc_scene *s, ray_t ray, inter_t in, const rng_c
     v3 ldir = light_direction(l, in.pt);
     double diffuse = o->mat.diff * dmax(0.0, -v_dot(norm, ldir) * L);
     double specular = o->mat.spec * L * pow(dmax(0.0, -v_dot(ldir, reflect.d)), o->mat.shiness);
-    colour = c_add(colour, c_mul(obj_colour, emissive + s->ambient * o->mat.ambient + diffuse + specular));
+    colour = c_add(colour, c_mul(obj_colour_, emissive + s->ambient * o->mat.ambient + diffuse + specular));
   }
   return colour;
 }
@@ -1458,7 +1638,7 @@ void orc_ppm_pass(orc_ppm *m, int pass_index)
         } else if (o->mat.reflW > 0) {
           path = obj_reflect_ray(o, path, hp, in.u, in.v);
         }
-        col_t oc = o->colour;                                             /* CBaseObject::colour, untextured */
+        col_t oc = obj_colour(o, hp, in.u, in.v);                         /* PhotonMapper.h:296, 312, 324 */
         double sc = (colour.r + colour.g + colour.b) / (oc.r + oc.g + oc.b);
         colour = c_div(c_add(colour, c_mul(oc, sc)), 2);
         in = first_inter_pt_bsp(s, path, 1); m->photon_segments++;

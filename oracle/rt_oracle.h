@@ -104,6 +104,18 @@ void orc_render_focusing(orc_scene *s, const orc_camera *c, double radius, int s
                          uint64_t seed, double *rgb, size_t first, size_t count, int threads,
                          int64_t *counters);
 
+/* Textures (Object.h:69-74): an image (rows x cols x 3 bytes B,G,R = cv::Mat CV_8UC3) is registered once and attached
+ * as texture (Object.h:198-203; scale = CInftyPlane textureScale, :773-779) or bump texture (:205-210, :781-787);
+ * triangles take their textureCoord (Object.h:342) in texel units. */
+int orc_add_texture_image(orc_scene *s, int rows, int cols, const unsigned char *bgr);
+int orc_obj_add_texture(orc_scene *s, int obj, int tex, double scale);
+int orc_obj_add_bump_texture(orc_scene *s, int obj, int tex, double scale);
+int orc_triangle_set_tex_coord(orc_scene *s, int obj, const double tc[6]);
+/* CScene::RotationalSurfaceToMesh (tex < 0, Scene.h:168-213) / RotationalSurfaceToMesh_Texture (Scene.h:215-266);
+ * returns the number of triangles added */
+int orc_rotational_surface_to_mesh(orc_scene *s, const double *prof, int n_prof, int u_num, int v_num, int tex,
+                                   const double center[3], const double mat[8], const double col[3]);
+
 /* Adaptive anti-aliasing: Camera.h:83-169 (focusing = 0) and Camera.h:201-280 (focusing = 1).
  * aa[6] = oversampleTimes, r0, depth / norm / type / colour thresholds (Camera.h:77-82). */
 void orc_render_antialiasing(orc_scene *s, const orc_camera *c, const double aa[6], int focusing, double radius, int spp,

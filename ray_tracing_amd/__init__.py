@@ -106,6 +106,13 @@ host.rth_add_bezier.argtypes = [_vp, _vp, d3, d8, d3]
 host.rth_add_rotational.argtypes = [_vp, _vp, C.c_int, d3, C.c_int, C.c_double, d8, d3]
 host.rth_add_triangle.argtypes = [_vp, _vp, _vp, d8, d3]
 host.rth_add_triangles.argtypes = [_vp, _vp, C.c_size_t, d8, d3]
+host.rth_add_triangle_tex.argtypes = [_vp, _vp, _vp, _vp, d8, d3, C.POINTER(C.c_int)]
+host.rth_add_texture_image.argtypes = [_vp, C.c_uint, C.c_uint, _vp, C.POINTER(C.c_int)]
+host.rth_read_ppm_texture.argtypes = [_vp, C.c_char_p, C.POINTER(C.c_int)]
+host.rth_texture_info.argtypes = [_vp, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.POINTER(C.c_uint8))]
+host.rth_obj_add_texture.argtypes = [_vp, C.c_int, C.c_int, C.c_double]
+host.rth_obj_add_bump_texture.argtypes = [_vp, C.c_int, C.c_int, C.c_double]
+host.rth_rotational_surface_to_mesh.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, d3, d8, d3, C.POINTER(C.c_int)]
 host.rth_read_obj_triangle.argtypes = [_vp, C.c_char_p, d3, C.c_double, d8, d3, C.POINTER(C.c_int)]
 host.rth_add_point_light.argtypes = [_vp, d3, C.c_double]
 host.rth_add_parallel_light.argtypes = [_vp, d3, C.c_double]
@@ -327,6 +334,14 @@ class SharedScene:
             self.raw = None
 
 
+def load_image(path):
+    """cv::imread stand-in for the Python host: any file PIL decodes -> (rows, cols, 3) uint8 in B,G,R order.
+    (JPEG decoders differ in the last bit; results are pinned on images given as arrays.)"""
+    from PIL import Image
+    rgb = np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
 class Scene:
     """rt::host::Scene (the CScene mirror)"""
 
@@ -366,6 +381,52 @@ class Scene:
     def add_triangles(self, v, mat, colour):
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, 9)
         _chk_host(host.rth_add_triangles(self._h, v.ctypes.data, v.shape[0], mat, d3(*colour)))
+
+    def add_triangle_tex(self, v, vn, tex_coord, mat, colour):
+        """CTriangle with textureCoord (Object.h:386-400): three (row, col) pairs in texel units"""
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(9)
+        tc = np.ascontiguousarray(tex_coord, dtype=np.float64).reshape(6)
+        vnp = None
+        if vn is not None:
+            vn = np.ascontiguousarray(vn, dtype=np.float64).reshape(9)
+            vnp = vn.ctypes.data
+        out = C.c_int(-1)
+        _chk_host(host.rth_add_triangle_tex(self._h, v.ctypes.data, vnp, tc.ctypes.data, mat, d3(*colour), C.byref(out)))
+        return out.value
+
+    def add_texture_image(self, bgr):
+        """registers a (rows, cols, 3) uint8 B,G,R image (cv::Mat CV_8UC3 of cv::imread); returns its index"""
+        a = np.ascontiguousarray(bgr, dtype=np.uint8)
+        assert a.ndim == 3 and a.shape[2] == 3
+        out = C.c_int(-1)
+        _chk_host(host.rth_add_texture_image(self._h, a.shape[0], a.shape[1], a.ctypes.data, C.byref(out)))
+        return out.value
+
+    def read_ppm_texture(self, path):
+        out = C.c_int(-1)
+        _chk_host(host.rth_read_ppm_texture(self._h, os.fsencode(path), C.byref(out)))
+        return out.value
+
+    def texture_image(self, tex):
+        rows, cols, p = C.c_uint(), C.c_uint(), C.POINTER(C.c_uint8)()
+        _chk_host(host.rth_texture_info(self._h, tex, C.byref(rows), C.byref(cols), C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(rows.value, cols.value, 3)).copy()
+
+    def add_texture(self, obj, tex, scale=1.0):
+        """CBaseObject::AddTexture / CInftyPlane::AddTexture(file, textureScale)"""
+        _chk_host(host.rth_obj_add_texture(self._h, obj, tex, float(scale)))
+
+    def add_bump_texture(self, obj, tex, scale=1.0):
+        """CBaseObject::AddBumpTexture / CInftyPlane::AddBumpTexture(file, bumpTextureScale)"""
+        _chk_host(host.rth_obj_add_bump_texture(self._h, obj, tex, float(scale)))
+
+    def rotational_surface_to_mesh(self, profile, u_num, v_num, center, mat, colour, tex=-1):
+        """CScene::RotationalSurfaceToMesh / RotationalSurfaceToMesh_Texture (Scene.h:168-266); returns the triangles added"""
+        pr = np.ascontiguousarray(profile, dtype=np.float64).reshape(-1, 2)
+        n = C.c_int(0)
+        _chk_host(host.rth_rotational_surface_to_mesh(self._h, pr.ctypes.data, pr.shape[0], int(u_num), int(v_num), int(tex), d3(*center), mat,
+                                                     d3(*colour), C.byref(n)))
+        return n.value
 
     def read_obj_triangle(self, path, center, scale, mat, colour):
         n = C.c_int(0)

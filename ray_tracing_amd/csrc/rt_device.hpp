@@ -71,6 +71,7 @@ struct DSphere { double c[3], r; };
 struct DCircle { double p0[3], n[3], r; };
 struct DMaterial { double reflW, refrW, RI, diff, spec, shiness, emissive, ambient; };
 struct DLight { int32_t type, sample_num; double p[3], lum, len, lum_per_sample; };
+struct DTexture { const uint8_t *bgr; int32_t rows, cols; };           // cv::Mat CV_8UC3: bgr[(row * cols + col) * 3 + {B,G,R}]
 
 struct DevScene {
   const DPair *pairs; const unsigned char *leaf_stream;
@@ -82,6 +83,10 @@ struct DevScene {
   int32_t has_param;                            // the scene holds Bezier / rotational objects: kernels built with PARAM
   const uint8_t *obj_type; const uint32_t *obj_index; const uint32_t *obj_mat; const double *obj_colour;
   int32_t n_objects;
+  // textures (Object.h:69-74); obj_tex == NULL: no object of the scene has one
+  const DTexture *textures; const int32_t *obj_tex; const int32_t *obj_bump;   // per object: texture index or -1
+  const double *obj_tex_scale;                                                 // per object: textureScale, bumpTextureScale (CInftyPlane)
+  const double *tri_uv;                                                        // per triangle: textureCoord[3] (u, v), or NULL
   const DMaterial *materials;
   const DLight *lights; int32_t n_lights;
   double ambient;
@@ -645,7 +650,7 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
 // hidden cur_u / cur_v state, which a later intersection can overwrite before ReflectRay runs; here
 // the hit record carries them, so the normal always belongs to the hit being shaded.
 template <bool PARAM = false>
-__device__ __forceinline__ V3 object_norm(const DevScene &sc, int id, V3 pt, double hu = kInfty, double hv = kInfty)
+__device__ __forceinline__ V3 object_initial_norm(const DevScene &sc, int id, V3 pt, double hu = kInfty, double hv = kInfty)
 {
   const int type = sc.obj_type[id];
   const uint32_t k = sc.obj_index[id];
@@ -673,6 +678,134 @@ __device__ __forceinline__ V3 object_norm(const DevScene &sc, int id, V3 pt, dou
     const DCircle &C = sc.circles[k]; return mk(C.n[0], C.n[1], C.n[2]);
   }
   return infty_pt();
+}
+
+// ---- textures (Object.h:79-92, 186-196; per type :280-319, 470-486, 725-771, 810-813, 1051-1054) ----
+// texture->at<cv::Vec3b>(row, col) with the indices clamped into the image: the reference reads out of bounds when an
+// index reaches rows / cols (e.g. u0 == 1 on a sphere's pole).  The angle of a hit on a surface of revolution is
+// whatever real number Newton's iteration ended on (also negative, also beyond 2 PI): its column wraps around.
+struct Texel { double b, g, r; };
+__device__ __forceinline__ Texel texel_at(const DTexture &T, int row, int col)
+{
+  row = row < 0 ? 0 : (row >= T.rows ? T.rows - 1 : row);
+  col = col < 0 ? 0 : (col >= T.cols ? T.cols - 1 : col);
+  const uint8_t *q = T.bgr + ((size_t)row * T.cols + col) * 3;
+  Texel t; t.b = q[0]; t.g = q[1]; t.r = q[2];
+  return t;
+}
+__device__ __forceinline__ int to_int(double x)      // int(double) of the reference, defined for every input
+{
+  if (!(x > -2147483648.0)) return -2147483647 - 1;
+  if (!(x < 2147483647.0)) return 2147483647;
+  return (int)x;
+}
+// CInftyPlane's in-plane axis u0 (Object.h:727-734, 746-753, 762-770)
+__device__ __forceinline__ V3 plane_u0(V3 n)
+{
+  const V3 a = mk(1, 0, 0), b = mk(0, 1, 0), c = mk(0, 0, 1);
+  if (fabs(dot(a, n)) < 0.5) return unitize(a - n * dot(a, n));
+  if (fabs(dot(b, n)) < 0.5) return unitize(b - n * dot(b, n));
+  return unitize(c - n * dot(c, n));
+}
+// CTriangle::UV_colour / UV_norm (Object.h:470-486): the same area-weighted textureCoord
+__device__ __forceinline__ void tri_uv_at(const DevScene &sc, uint32_t k, V3 pt, double &u, double &v)
+{
+  const TriExact &T = sc.tri_exact[k];
+  V3 v0 = mk(T.v0[0], T.v0[1], T.v0[2]), v1 = mk(T.v1[0], T.v1[1], T.v1[2]), v2 = mk(T.v2[0], T.v2[1], T.v2[2]);
+  double S0 = len(cross(v1 - pt, v2 - pt));
+  double S1 = len(cross(v0 - pt, v2 - pt));
+  double S2 = len(cross(v0 - pt, v1 - pt));
+  double Sa = len(cross(v1 - v0, v2 - v0));
+  const double *c = sc.tri_uv + 6 * (size_t)k;
+  // CPoint2D * double, + (Geometry.h:149-151), left to right
+  u = c[0] * (S0 / Sa) + c[2] * (S1 / Sa) + c[4] * (S2 / Sa);
+  v = c[1] * (S0 / Sa) + c[3] * (S1 / Sa) + c[5] * (S2 / Sa);
+}
+// CSphere::UV_norm (Object.h:289-296); UV_colour scales it by rows / cols (:280-287)
+__device__ __forceinline__ void sphere_uv(const DSphere &S, V3 pt, double &u0, double &v0)
+{
+  if (pt.x == 0 && pt.y == 0) { u0 = 0; v0 = 0; return; }
+  const V3 q = pt - mk(S.c[0], S.c[1], S.c[2]);
+  v0 = (atan2(q.y, q.x) + kPiRef) / (2 * kPiRef);
+  u0 = (asin(q.z / S.r) + kPiRef / 2) / kPiRef;
+}
+
+// CBaseObject::colour (Object.h:186-196)
+template <bool PARAM = false>
+__device__ __forceinline__ Col object_colour(const DevScene &sc, int id, V3 pt, double hu = kInfty, double hv = kInfty)
+{
+  const int ti = sc.obj_tex ? sc.obj_tex[id] : -1;
+  if (ti < 0) return mkc(sc.obj_colour[3 * id], sc.obj_colour[3 * id + 1], sc.obj_colour[3 * id + 2]);
+  const DTexture T = sc.textures[ti];
+  const int type = sc.obj_type[id];
+  const uint32_t k = sc.obj_index[id];
+  double u = 0, v = 0;                                  // CBaseObject::UV_colour default: CPoint2D() (Object.h:61)
+  if (type == 0) {                                      // Object.h:280-287
+    double u0, v0; sphere_uv(sc.spheres[k], pt, u0, v0);
+    u = to_int(u0 * T.rows); v = to_int(v0 * T.cols);
+    if (pt.x == 0 && pt.y == 0) { u = 0; v = 0; }
+  } else if (type == 1) {                               // Object.h:470-477
+    if (sc.tri_uv) tri_uv_at(sc, k, pt, u, v);
+  } else if (type == 4) {                               // Object.h:725-742
+    const DPlane &P = sc.planes[k];
+    const V3 n = mk(P.n[0], P.n[1], P.n[2]), u0 = plane_u0(n), v0 = cross(n, u0);
+    const V3 rel = pt - mk(P.p0[0], P.p0[1], P.p0[2]);
+    const double scale = sc.obj_tex_scale[2 * id];
+    int up = to_int(dot(rel, u0) * scale) % T.rows, vp = to_int(dot(rel, v0) * scale) % T.cols;
+    up = (up + T.rows) % T.rows; vp = (vp + T.cols) % T.cols;
+    u = up; v = vp;
+  } else if (PARAM && type == 5) {                      // Object.h:810; theta of the Newton root is any real: column taken modulo cols
+    u = to_int(hu * T.rows);
+    int vc = to_int(hv * T.cols / (2 * kPiRef)) % T.cols;
+    v = (vc + T.cols) % T.cols;
+  } else if (PARAM && type == 6) {                      // Object.h:1051
+    u = to_int(hu * T.rows); v = to_int(hv * T.cols);
+  }
+  const Texel c = texel_at(T, to_int(u), to_int(v));    // Object.h:193
+  return mkc(c.r, c.g, c.b);                            // Object.h:194
+}
+
+// CBaseObject::Norm (Object.h:79-92): InitialNorm, perturbed by the bump texture when the object has one
+template <bool PARAM = false>
+__device__ __forceinline__ V3 object_norm(const DevScene &sc, int id, V3 pt, double hu = kInfty, double hv = kInfty)
+{
+  const V3 N = object_initial_norm<PARAM>(sc, id, pt, hu, hv);
+  const int bi = sc.obj_bump ? sc.obj_bump[id] : -1;
+  if (bi < 0) return N;
+  const DTexture T = sc.textures[bi];
+  const int type = sc.obj_type[id];
+  const uint32_t k = sc.obj_index[id];
+  double u = 0, v = 0;                                  // CBaseObject::UV_norm / Tangent / Bitangent defaults (Object.h:62-64)
+  V3 tan = mk(0, 0, 0), bit = mk(0, 0, 0);
+  if (type == 0) {                                      // Object.h:289-319
+    const DSphere &S = sc.spheres[k];
+    sphere_uv(S, pt, u, v);
+    tan = unitize(mk(-2 * kPiRef * S.r * sin(2 * kPiRef * v - kPiRef) * cos(kPiRef * u - kPiRef / 2),
+                     2 * kPiRef * S.r * cos(2 * kPiRef * v - kPiRef) * cos(kPiRef * u - kPiRef / 2), 0));
+    bit = unitize(mk(-kPiRef * S.r * cos(2 * kPiRef * v - kPiRef) * sin(kPiRef * u - kPiRef / 2),
+                     -kPiRef * S.r * sin(2 * kPiRef * v - kPiRef) * sin(kPiRef * u - kPiRef / 2),
+                     kPiRef * S.r * cos(kPiRef * u - kPiRef / 2)));
+  } else if (type == 1) {                               // Object.h:479-486; no Tangent / Bitangent override
+    if (sc.tri_uv) tri_uv_at(sc, k, pt, u, v);
+  } else if (type == 4) {                               // Object.h:744-771, 700
+    const DPlane &P = sc.planes[k];
+    const V3 n = mk(P.n[0], P.n[1], P.n[2]), u0 = plane_u0(n), v0 = cross(n, u0);
+    const V3 rel = pt - mk(P.p0[0], P.p0[1], P.p0[2]);
+    const double scale = sc.obj_tex_scale[2 * id + 1];
+    const double a = dot(rel, u0) / scale, b = dot(rel, v0) / scale;
+    u = a - floor(a); v = b - floor(b);
+    tan = u0; bit = cross(n, u0);
+  } else if (PARAM && type == 5) {                      // Object.h:811-813
+    const DRotational &R = sc.rotationals[k];
+    u = hu; v = hv / (2 * kPiRef); v = v - floor(v);    // theta of the Newton root is any real: one turn = one image width
+    tan = unitize(rot_ds_dth(R, hu, hv)); bit = unitize(rot_ds_dt(R, hu, hv));
+  } else if (PARAM && type == 6) {                      // Object.h:1052-1054
+    V3 S, du, dv; bez_eval(sc.beziers[k], hu, hv, S, du, dv);
+    u = hu; v = hv;
+    tan = unitize(du); bit = unitize(dv);
+  }
+  const Texel c = texel_at(T, to_int(u * T.rows), to_int(v * T.cols));     // Object.h:87
+  return unitize(bit * (c.r / 127.5 - 1) + tan * (c.g / 127.5 - 1) + N * (c.b / 127.5 - 1));   // Object.h:88-90
 }
 
 // CBaseObject::ReflectRay direction, Object.h:94-101 (Unitize twice: :100 and the CRay ctor)
@@ -760,7 +893,7 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
   return lum;
 }
 
-// CScene::LocalIllumination, Scene.h:93-122 (untextured: objColour = m_colour).  lum[li] = luminosity of
+// CScene::LocalIllumination, Scene.h:93-122.  lum[li] = luminosity of
 // light li at pt, computed beforehand by the shadow pass (light_luminosity).
 template <bool PARAM = false>
 __device__ __forceinline__ Col local_illumination(const DevScene &sc, V3 d, int id, V3 pt, const double *lum, V3 &N_out,
@@ -772,7 +905,7 @@ __device__ __forceinline__ Col local_illumination(const DevScene &sc, V3 d, int 
   V3 norm = N;
   if (dot(d, norm) > kEps) norm = neg(norm);
   const DMaterial M = sc.materials[sc.obj_mat[id]];
-  const Col oc = mkc(sc.obj_colour[3 * id], sc.obj_colour[3 * id + 1], sc.obj_colour[3 * id + 2]);
+  const Col oc = object_colour<PARAM>(sc, id, pt, hu, hv);         // Scene.h:101
   const V3 refl = reflect_dir(N, d);
   for (int li = 0; li < sc.n_lights; li++) {
     const DLight &L = sc.lights[li];

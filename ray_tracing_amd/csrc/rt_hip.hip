@@ -853,6 +853,20 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
     if (z.u_sample_num < 1 || z.u_sample_num > 4096) return fail(RT_HIP_EINVAL, "rotational object: u_sample_num out of range [1, 4096]");
   }
   if (d->n_lights > 16) return fail(RT_HIP_EUNSUPPORTED, "more than 16 lights");
+  if (d->n_textures) {
+    if (!d->textures || !d->obj_texture || !d->obj_bump_texture) return fail(RT_HIP_EINVAL, "texture arrays missing");
+    for (uint32_t k = 0; k < d->n_textures; k++)
+      if (!d->textures[k].bgr || d->textures[k].rows == 0 || d->textures[k].cols == 0 || d->textures[k].rows > 32768 || d->textures[k].cols > 32768)
+        return fail(RT_HIP_EINVAL, "texture " + std::to_string(k) + ": empty or larger than 32768 x 32768");
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+      const int32_t t = d->obj_texture[i], b = d->obj_bump_texture[i];
+      if (t < -1 || t >= (int32_t)d->n_textures || b < -1 || b >= (int32_t)d->n_textures) return fail(RT_HIP_EINVAL, "object texture index out of range");
+      if (d->obj_type[i] == RT_HIP_INFTY_PLANE && (t >= 0 || b >= 0)) {
+        if (!d->obj_texture_scale) return fail(RT_HIP_EINVAL, "obj_texture_scale missing for a textured plane");
+        if (b >= 0 && !(d->obj_texture_scale[2 * i + 1] != 0)) return fail(RT_HIP_EINVAL, "bumpTextureScale of a plane must not be 0");
+      }
+    }
+  }
   for (uint32_t i = 0; i < d->n_objects; i++) {
     uint32_t k = d->obj_index[i], lim = 0;
     switch (d->obj_type[i]) {
@@ -953,6 +967,24 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   DevScene &D = s->dev;
   int rc = RT_HIP_OK;
   auto up = [&](int r) { if (rc == RT_HIP_OK) rc = r; };
+  if (d->n_textures) {
+    // cv::Mat images of Object.h:70-73, one allocation each; the per-object tables only exist for textured scenes
+    std::vector<DTexture> tex(d->n_textures);
+    for (uint32_t k = 0; k < d->n_textures && rc == RT_HIP_OK; k++) {
+      const rt_hip_texture &t = d->textures[k];
+      std::vector<uint8_t> px(t.bgr, t.bgr + (size_t)t.rows * t.cols * 3);
+      up(upload(s, px, &tex[k].bgr));
+      tex[k].rows = (int32_t)t.rows; tex[k].cols = (int32_t)t.cols;
+    }
+    std::vector<int32_t> otex(d->obj_texture, d->obj_texture + d->n_objects), obump(d->obj_bump_texture, d->obj_bump_texture + d->n_objects);
+    std::vector<double> oscale(2 * (size_t)d->n_objects, 1.0);
+    if (d->obj_texture_scale) oscale.assign(d->obj_texture_scale, d->obj_texture_scale + 2 * (size_t)d->n_objects);
+    up(upload(s, tex, &D.textures)); up(upload(s, otex, &D.obj_tex)); up(upload(s, obump, &D.obj_bump)); up(upload(s, oscale, &D.obj_tex_scale));
+    if (d->tri_texture_coord && d->n_triangles) {
+      std::vector<double> tuv(d->tri_texture_coord, d->tri_texture_coord + 6 * (size_t)d->n_triangles);
+      up(upload(s, tuv, &D.tri_uv));
+    }
+  }
   up(upload(s, B.pairs, &D.pairs)); up(upload(s, B.stream, &D.leaf_stream));
   up(upload(s, root_objs, &D.root_objs)); up(upload(s, B.tri_exact, &D.tri_exact)); up(upload(s, tri_shade, &D.tri_shade));
   up(upload(s, planes, &D.planes)); up(upload(s, spheres, &D.spheres)); up(upload(s, circles, &D.circles));

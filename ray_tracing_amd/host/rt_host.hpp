@@ -127,6 +127,69 @@ struct ObjMesh {
   }
 };
 
+// cv::Mat CV_8UC3 as cv::imread returns it (Object.h:198-210): rows x cols, B,G,R bytes.  Decoding JPEG / PNG is the
+// application's business (the reference leaves it to OpenCV); binary PPM is read here for C++ layouts and tests.
+struct Image {
+  uint32_t rows = 0, cols = 0;
+  std::vector<uint8_t> bgr;
+  Image() {}
+  Image(uint32_t r, uint32_t c, const uint8_t *data) : rows(r), cols(c), bgr(data, data + (size_t)r * c * 3) {}
+  static Image ReadPPM(const std::string &path)
+  {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    auto token = [&](long &out) {                        // header integers, '#' comments skipped
+      int ch = std::fgetc(f);
+      for (;;) {
+        while (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r') ch = std::fgetc(f);
+        if (ch != '#') break;
+        while (ch != '\n' && ch != EOF) ch = std::fgetc(f);
+      }
+      if (ch < '0' || ch > '9') return false;
+      out = 0;
+      while (ch >= '0' && ch <= '9') { out = out * 10 + (ch - '0'); ch = std::fgetc(f); }
+      return true;                                      // the single whitespace after the token is consumed
+    };
+    Image im; long w = 0, h = 0, mx = 0;
+    bool ok = std::fgetc(f) == 'P' && std::fgetc(f) == '6' && token(w) && token(h) && token(mx) && w > 0 && h > 0 && mx == 255 &&
+              w <= 32768 && h <= 32768;
+    if (ok) {
+      im.rows = (uint32_t)h; im.cols = (uint32_t)w; im.bgr.resize((size_t)w * h * 3);
+      ok = std::fread(im.bgr.data(), 1, im.bgr.size(), f) == im.bgr.size();
+      for (size_t i = 0; ok && i < (size_t)w * h; i++) std::swap(im.bgr[3 * i], im.bgr[3 * i + 2]);    // RGB -> BGR
+    }
+    std::fclose(f);
+    if (!ok) throw std::runtime_error("not a binary 8-bit PPM: " + path);
+    return im;
+  }
+};
+
+// CBezierCurve + CRotationalSurface (Bezier.h:8-87): the profile curve P(t) = (radius, height) and the surface
+// S(t, theta) it sweeps about the z axis; used on the host by RotationalSurfaceToMesh
+struct RotationalSurface {
+  std::vector<std::array<double, 2>> controlPts;         // AddControlPt order (Bezier.h:19)
+  void AddControlPt(double u, double v) { controlPts.push_back({u, v}); }
+  int degree() const { return (int)controlPts.size() - 1; }
+  std::array<double, 2> Point2D(double t, int i, int deg) const                               // Bezier.h:28-34
+  {
+    if (deg == 0) return controlPts[i];
+    auto a = Point2D(t, i, deg - 1), b = Point2D(t, i + 1, deg - 1);
+    return {a[0] * (1 - t) + b[0] * t, a[1] * (1 - t) + b[1] * t};
+  }
+  std::array<double, 2> TanVec(double t) const                                                // Bezier.h:36-39
+  { auto a = Point2D(t, 1, degree() - 1), b = Point2D(t, 0, degree() - 1); return {(a[0] - b[0]) * degree(), (a[1] - b[1]) * degree()}; }
+  std::array<double, 2> Norm2D(double t) const                                                // Bezier.h:41-45, Geometry.h:219-225
+  {
+    auto tv = TanVec(t);
+    double u = tv[1], v = -(tv[0]);
+    if ((std::fabs(u) < eps && std::fabs(v) < eps) || (std::fabs(u - infty) < eps && std::fabs(v - infty) < eps)) return {infty, infty};
+    double l = std::sqrt(u * u + v * v);
+    return {u / l, v / l};
+  }
+  Point3D Point3D_(double t, double th) const { auto p = Point2D(t, 0, degree()); return Point3D(p[0] * std::cos(th), p[0] * std::sin(th), p[1]); }   // Bezier.h:65-69
+  Point3D Norm(double t, double th) const { auto r = Norm2D(t); return Point3D(r[0] * std::cos(th), r[0] * std::sin(th), r[1]).Unitize(); }         // Bezier.h:71-75
+};
+
 class Scene {                    // CScene, Scene.h:12-60
  public:
   explicit Scene(double ambient = 0) : ambient_(ambient) {}
@@ -146,8 +209,38 @@ class Scene {                    // CScene, Scene.h:12-60
     for (int i = 0; i < 3; i++) { t.v[i][0] = v[i].x; t.v[i][1] = v[i].y; t.v[i][2] = v[i].z; }
     if (vn) { for (int i = 0; i < 3; i++) { t.vn[i][0] = vn[i].x; t.vn[i][1] = vn[i].y; t.vn[i][2] = vn[i].z; } t.has_vn = 1; }
     triangles_.push_back(t);
+    for (int i = 0; i < 6; i++) tri_tex_coord_.push_back(0.0);
     return add(RT_HIP_TRIANGLE, (uint32_t)triangles_.size() - 1, m, col);
   }
+  // CTriangle(vertex, vertexNorm, textureCoord, ...), Object.h:386-400: textureCoord in texel units (row, col)
+  int AddTriangle(const Point3D v[3], const Point3D *vn, const double textureCoord[3][2], const Material &m, Colour col)
+  {
+    int id = AddTriangle(v, vn, m, col);
+    for (int i = 0; i < 3; i++) { tri_tex_coord_[tri_tex_coord_.size() - 6 + 2 * i] = textureCoord[i][0]; tri_tex_coord_[tri_tex_coord_.size() - 6 + 2 * i + 1] = textureCoord[i][1]; }
+    return id;
+  }
+  // ---- textures: an image is registered once (the reference shares one cv::Mat* between objects, Scene.h:243) ----
+  int AddTextureImage(const Image &img)
+  {
+    if (img.rows == 0 || img.cols == 0 || img.bgr.size() != (size_t)img.rows * img.cols * 3) throw std::runtime_error("empty or inconsistent texture image");
+    images_.push_back(img); dirty_ = true;
+    return (int)images_.size() - 1;
+  }
+  const Image &TextureImage(int tex) const { return images_.at((size_t)tex); }
+  // CBaseObject::AddTexture (Object.h:198-203) / CInftyPlane::AddTexture(filename, textureScale) (Object.h:773-779)
+  void AddTexture(int obj, int tex, double textureScale = 1)
+  { check_obj_tex(obj, tex); obj_tex_[(size_t)obj] = tex; obj_tex_scale_[2 * (size_t)obj] = textureScale; dirty_ = true; }
+  // CBaseObject::AddBumpTexture (Object.h:205-210) / CInftyPlane::AddBumpTexture(filename, bumpTextureScale) (Object.h:781-787)
+  void AddBumpTexture(int obj, int tex, double bumpTextureScale = 1)
+  { check_obj_tex(obj, tex); obj_bump_[(size_t)obj] = tex; obj_tex_scale_[2 * (size_t)obj + 1] = bumpTextureScale; dirty_ = true; }
+  // Scene.h:168-213: the surface of revolution as (uNum x vNum x 2) triangles with vertex normals.  The loops run on
+  // accumulated doubles exactly as the reference's do (u += du, v += dv, snapped to 1 and 2 PI within 100 eps).
+  int RotationalSurfaceToMesh(const RotationalSurface &surface, int uNum, int vNum, Point3D center, const Material &m, Colour col)
+  { return rot_to_mesh(surface, uNum, vNum, -1, center, m, col); }
+  // Scene.h:215-266: the same with textureCoord = (u rows, v cols / 2 PI) per vertex and the texture on every triangle
+  // (no snapping of u, v in this variant)
+  int RotationalSurfaceToMesh_Texture(const RotationalSurface &surface, int uNum, int vNum, int tex, Point3D center, const Material &m, Colour col)
+  { if (tex < 0 || (size_t)tex >= images_.size()) throw std::runtime_error("texture index out of range"); return rot_to_mesh(surface, uNum, vNum, tex, center, m, col); }
   // CBezierObject(controlPts[4][4], center, material, colour), Object.h:1075
   int AddBezierObject(const Point3D ctrl[4][4], Point3D center, const Material &m, Colour col)
   {
@@ -241,6 +334,13 @@ class Scene {                    // CScene, Scene.h:12-60
     d.n_root_objects = (uint32_t)root_objects_.size(); d.root_objects = root_objects_.data();
     d.n_beziers = (uint32_t)beziers_.size(); d.beziers = beziers_.data();
     d.n_rotationals = (uint32_t)rotationals_.size(); d.rotationals = rotationals_.data();
+    std::vector<rt_hip_texture> tex(images_.size());
+    for (size_t k = 0; k < images_.size(); k++) tex[k] = rt_hip_texture{images_[k].rows, images_[k].cols, images_[k].bgr.data()};
+    if (!images_.empty()) {
+      d.n_textures = (uint32_t)tex.size(); d.textures = tex.data();
+      d.obj_texture = obj_tex_.data(); d.obj_bump_texture = obj_bump_.data(); d.obj_texture_scale = obj_tex_scale_.data();
+      d.tri_texture_coord = tri_tex_coord_.data();
+    }
     check(rt_hip_scene_create(ctx.get(), &d, leaf_refine_, &dev_), "rt_hip_scene_create");
     dev_ctx_ = ctx.get(); dirty_ = false;
     return dev_;
@@ -262,8 +362,46 @@ class Scene {                    // CScene, Scene.h:12-60
     if (mi == materials_.size()) materials_.push_back(m.m);
     mat_index_.push_back(mi);
     colour_.push_back(col.R); colour_.push_back(col.G); colour_.push_back(col.B);
+    obj_tex_.push_back(-1); obj_bump_.push_back(-1); obj_tex_scale_.push_back(1.0); obj_tex_scale_.push_back(1.0);
     dirty_ = true;
     return (int)type_.size() - 1;
+  }
+  void check_obj_tex(int obj, int tex) const
+  {
+    if (obj < 0 || (size_t)obj >= type_.size()) throw std::runtime_error("object id out of range");
+    if (tex < 0 || (size_t)tex >= images_.size()) throw std::runtime_error("texture index out of range");
+  }
+  int rot_to_mesh(const RotationalSurface &surface, int uNum, int vNum, int tex, Point3D center, const Material &m, Colour col)
+  {
+    const double PI = 3.1415926535;                                                        // Geometry.h:13
+    if (uNum < 1 || vNum < 1 || surface.degree() < 1) throw std::runtime_error("RotationalSurfaceToMesh: bad arguments");
+    std::vector<Point3D> points, normals;
+    const double du = 1 / double(uNum), dv = 2 * PI / double(vNum);
+    const double rows = tex >= 0 ? (double)images_[(size_t)tex].rows : 0, cols = tex >= 0 ? (double)images_[(size_t)tex].cols : 0;
+    long ptId = 0; int added = 0;
+    for (double u = 0, i = 0; u < 1 + eps; u += du, i++) {
+      if (tex < 0 && std::fabs(u - 1) < 100 * eps) u = 1;                                  // Scene.h:177-178 (plain variant only)
+      for (double v = 0, j = 0; v < 2 * PI + eps; v += dv, j++) {
+        if (tex < 0 && std::fabs(v - 2 * PI) < 100 * eps) v = 2 * PI;                      // Scene.h:181-182
+        points.push_back(surface.Point3D_(u, v));
+        normals.push_back(surface.Norm(u, v));
+        if (i != 0 && j != 0) {
+          if (ptId - vNum - 2 < 0) throw std::runtime_error("RotationalSurfaceToMesh: the v loop did not run vNum + 1 times");
+          const long a = ptId, b = ptId - 1, c = ptId - vNum - 1, d = ptId - vNum - 2;
+          Point3D v1[3] = {points[a] + center, points[b] + center, points[c] + center}, n1[3] = {normals[a], normals[b], normals[c]};
+          Point3D v2[3] = {points[b] + center, points[d] + center, points[c] + center}, n2[3] = {normals[b], normals[d], normals[c]};
+          if (tex >= 0) {
+            const double t1[3][2] = {{u * rows, v * cols / (2 * PI)}, {u * rows, (v - dv) * cols / (2 * PI)}, {(u - du) * rows, v * cols / (2 * PI)}};
+            const double t2[3][2] = {{u * rows, (v - dv) * cols / (2 * PI)}, {(u - du) * rows, (v - dv) * cols / (2 * PI)}, {(u - du) * rows, v * cols / (2 * PI)}};
+            AddTexture(AddTriangle(v1, n1, t1, m, col), tex);
+            AddTexture(AddTriangle(v2, n2, t2, m, col), tex);
+          } else { AddTriangle(v1, n1, m, col); AddTriangle(v2, n2, m, col); }
+          added += 2;
+        }
+        ptId++;
+      }
+    }
+    return added;
   }
   static bool is_infty_box(const Box &b)
   { for (int a = 0; a < 3; a++) if (!(std::fabs(b.mn[a] - infty) < eps && std::fabs(b.mx[a] - infty) < eps)) return false; return true; }
@@ -362,6 +500,7 @@ class Scene {                    // CScene, Scene.h:12-60
   std::vector<rt_hip_triangle> triangles_; std::vector<rt_hip_plane> planes_; std::vector<rt_hip_sphere> spheres_;
   std::vector<rt_hip_circle> circles_; std::vector<rt_hip_material> materials_; std::vector<rt_hip_light> lights_;
   std::vector<rt_hip_bezier> beziers_; std::vector<rt_hip_rotational> rotationals_;
+  std::vector<Image> images_; std::vector<int32_t> obj_tex_, obj_bump_; std::vector<double> obj_tex_scale_, tri_tex_coord_;
   std::vector<Box> boxes_;
   std::vector<rt_hip_node> nodes_; std::vector<uint32_t> refs_, root_objects_;
   int max_obj_ = 100, max_depth_ = 40;

@@ -60,6 +60,34 @@ int rth_add_triangles(void *s, const double *v, size_t n, const double m[8], con
   Material mm = mat_from(m); Colour c(col[0], col[1], col[2]);
   GUARD(for (size_t k = 0; k < n; k++) { Point3D p[3]; for (int i = 0; i < 3; i++) p[i] = Point3D(v[9 * k + 3 * i], v[9 * k + 3 * i + 1], v[9 * k + 3 * i + 2]); ((Scene *)s)->AddTriangle(p, nullptr, mm, c); })
 }
+// textures: pixels = rows x cols x 3 bytes, B,G,R (cv::Mat CV_8UC3)
+int rth_add_texture_image(void *s, unsigned rows, unsigned cols, const unsigned char *bgr, int *tex)
+{ GUARD(*tex = ((Scene *)s)->AddTextureImage(Image(rows, cols, bgr))) }
+int rth_read_ppm_texture(void *s, const char *path, int *tex) { GUARD(*tex = ((Scene *)s)->AddTextureImage(Image::ReadPPM(path))) }
+int rth_texture_info(void *s, int tex, unsigned *rows, unsigned *cols, const unsigned char **bgr)
+{ GUARD(const Image &im = ((Scene *)s)->TextureImage(tex); *rows = im.rows; *cols = im.cols; *bgr = im.bgr.data()) }
+int rth_obj_add_texture(void *s, int obj, int tex, double scale) { GUARD(((Scene *)s)->AddTexture(obj, tex, scale)) }
+int rth_obj_add_bump_texture(void *s, int obj, int tex, double scale) { GUARD(((Scene *)s)->AddBumpTexture(obj, tex, scale)) }
+static int add_triangle_tex_impl(Scene *s, const double *v, const double *vn, const double *tc, const double *m, const double *col)
+{
+  Point3D p[3], q[3]; double t[3][2];
+  for (int i = 0; i < 3; i++) { p[i] = Point3D(v[3 * i], v[3 * i + 1], v[3 * i + 2]); if (vn) q[i] = Point3D(vn[3 * i], vn[3 * i + 1], vn[3 * i + 2]); t[i][0] = tc[2 * i]; t[i][1] = tc[2 * i + 1]; }
+  return s->AddTriangle(p, vn ? q : nullptr, t, mat_from(m), Colour(col[0], col[1], col[2]));
+}
+int rth_add_triangle_tex(void *s, const double v[9], const double *vn, const double tc[6], const double m[8], const double col[3], int *id)
+{ GUARD(*id = add_triangle_tex_impl((Scene *)s, v, vn, tc, m, col)) }
+static int rot_to_mesh_impl(Scene *s, const double *prof, int n_prof, int u_num, int v_num, int tex, const double *c, const double *m, const double *col)
+{
+  RotationalSurface surf;
+  for (int k = 0; k < n_prof; k++) surf.AddControlPt(prof[2 * k], prof[2 * k + 1]);
+  Point3D center(c[0], c[1], c[2]);
+  return tex >= 0 ? s->RotationalSurfaceToMesh_Texture(surf, u_num, v_num, tex, center, mat_from(m), Colour(col[0], col[1], col[2]))
+                  : s->RotationalSurfaceToMesh(surf, u_num, v_num, center, mat_from(m), Colour(col[0], col[1], col[2]));
+}
+// CScene::RotationalSurfaceToMesh (tex < 0) / RotationalSurfaceToMesh_Texture (Scene.h:168-266)
+int rth_rotational_surface_to_mesh(void *s, const double *prof, int n_prof, int u_num, int v_num, int tex, const double c[3], const double m[8],
+                                   const double col[3], int *added)
+{ GUARD(*added = rot_to_mesh_impl((Scene *)s, prof, n_prof, u_num, v_num, tex, c, m, col)) }
 int rth_read_obj_triangle(void *s, const char *path, const double c[3], double scale, const double m[8], const double col[3], int *added)
 { GUARD(*added = ((Scene *)s)->ReadObjFile_Triangle(path, Point3D(c[0], c[1], c[2]), scale, mat_from(m), Colour(col[0], col[1], col[2]))) }
 void rth_add_point_light(void *s, const double p[3], double lum) { ((Scene *)s)->AddPointLight(Point3D(p[0], p[1], p[2]), lum); }

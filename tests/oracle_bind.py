@@ -28,6 +28,11 @@ L.orc_add_sphere.argtypes = [_vp, d3, C.c_double, d8, d3]
 L.orc_add_plane.argtypes = [_vp, d3, d3, d8, d3]
 L.orc_add_circle.argtypes = [_vp, d3, d3, C.c_double, d8, d3]
 L.orc_add_triangle.argtypes = [_vp, _vp, _vp, d8, d3]
+L.orc_add_texture_image.argtypes = [_vp, C.c_int, C.c_int, _vp]
+L.orc_obj_add_texture.argtypes = [_vp, C.c_int, C.c_int, C.c_double]
+L.orc_obj_add_bump_texture.argtypes = [_vp, C.c_int, C.c_int, C.c_double]
+L.orc_triangle_set_tex_coord.argtypes = [_vp, C.c_int, _vp]
+L.orc_rotational_surface_to_mesh.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, d3, d8, d3]
 L.orc_add_bezier.argtypes = [_vp, _vp, d3, d8, d3]
 L.orc_add_rotational.argtypes = [_vp, _vp, C.c_int, d3, C.c_int, C.c_double, d8, d3]
 L.orc_read_obj_triangle.argtypes = [_vp, C.c_char_p, d3, C.c_double, d8, d3]
@@ -108,6 +113,30 @@ class OracleScene:
             vnp = vn.ctypes.data
         return L.orc_add_triangle(self.h, v.ctypes.data, vnp, mat, d3(*colour))
 
+    def add_triangle_tex(self, v, vn, tex_coord, mat, colour):
+        i = self.add_triangle(v, vn, mat, colour)
+        tc = np.ascontiguousarray(tex_coord, dtype=np.float64).reshape(6)
+        assert L.orc_triangle_set_tex_coord(self.h, i, tc.ctypes.data) == 0
+        return i
+
+    def add_texture_image(self, bgr):
+        a = np.ascontiguousarray(bgr, dtype=np.uint8)
+        t = L.orc_add_texture_image(self.h, a.shape[0], a.shape[1], a.ctypes.data)
+        assert t >= 0
+        return t
+
+    def add_texture(self, obj, tex, scale=1.0):
+        assert L.orc_obj_add_texture(self.h, obj, tex, float(scale)) == 0
+
+    def add_bump_texture(self, obj, tex, scale=1.0):
+        assert L.orc_obj_add_bump_texture(self.h, obj, tex, float(scale)) == 0
+
+    def rotational_surface_to_mesh(self, profile, u_num, v_num, center, mat, colour, tex=-1):
+        pr = np.ascontiguousarray(profile, dtype=np.float64).reshape(-1, 2)
+        n = L.orc_rotational_surface_to_mesh(self.h, pr.ctypes.data, pr.shape[0], int(u_num), int(v_num), int(tex), d3(*center), mat, d3(*colour))
+        assert n >= 0
+        return n
+
     def add_triangles(self, v, mat, colour):
         v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, 9)
         col = d3(*colour)
@@ -135,6 +164,13 @@ class OracleScene:
     @property
     def num_objects(self):
         return L.orc_num_objects(self.h)
+
+    def get_triangle(self, i):
+        """(v[9], vn[9]) of object i, or None when it is not a triangle"""
+        v, vn = np.zeros(9), np.zeros(9)
+        if L.orc_get_triangle(self.h, i, v.ctypes.data, vn.ctypes.data) < 0:
+            return None
+        return v, vn
 
     def tree_stats(self):
         st = (C.c_int64 * 8)()

@@ -30,7 +30,7 @@ class _Pair:
     def mat(self, name):
         return (self.rta.material(name) if self.g is not None else None, self.ob.material(name) if self.o is not None else None)
 
-    def call(self, fn, *args, mat=None, colour=None):
+    def call(self, fn, *args, mat=None, colour=None, **kw):
         out = None
         for side, m in ((self.g, mat[0] if mat else None), (self.o, mat[1] if mat else None)):
             if side is None:
@@ -38,7 +38,7 @@ class _Pair:
             a = list(args)
             if mat is not None:
                 a += [m, colour]
-            out = getattr(side, fn)(*a)
+            out = getattr(side, fn)(*a, **kw)
         return out
 
 
@@ -216,4 +216,70 @@ def build_room(gpu=True, oracle=True, mirror=True):
     P.call("read_obj_triangle", ICOSA_OBJ, (9, -2, 0), 0.003, mat=P.mat("metal" if mirror else "plastic"), colour=(241, 46, 24))
     P.call("construct_bsp")
     P.call("add_area_light", (-10, 20, 20), 2.0, 10.0, 2)
+    return P.g, P.o
+
+
+# ---- textures and RotationalSurfaceToMesh (N3) ------------------------------------------------------
+def synth_texture(rows, cols, seed, kind="colour"):
+    """deterministic (rows, cols, 3) uint8 B,G,R images standing in for the reference's JPEG assets: 'colour' = blocks
+    of random colours over a gradient, 'bump' = a normal map whose blue (N) channel stays dominant"""
+    rng = np.random.default_rng(seed)
+    r = np.arange(rows)[:, None]; c = np.arange(cols)[None, :]
+    if kind == "colour":
+        blocks = rng.integers(30, 255, size=((rows + 7) // 8, (cols + 7) // 8, 3))
+        img = np.kron(blocks, np.ones((8, 8, 1), dtype=np.int64))[:rows, :cols]
+        img = (img * 0.7 + 0.3 * ((r * 255 // max(1, rows - 1) + c * 255 // max(1, cols - 1)) // 2)[..., None]).astype(np.uint8)
+        return np.ascontiguousarray(img)
+    img = np.zeros((rows, cols, 3), dtype=np.uint8)
+    img[..., 0] = 200 + rng.integers(0, 55, size=(rows, cols))                       # B -> N
+    img[..., 1] = (127.5 + 90 * np.sin(r * 0.7) * np.cos(c * 0.45)).astype(np.uint8)  # G -> tangent
+    img[..., 2] = (127.5 + 90 * np.cos(r * 0.31 + c * 0.53)).astype(np.uint8)         # R -> bitangent
+    return img
+
+
+APPLE_PROFILE = [(0, 0.3), (2.2, -0.9), (2.6, 2.4), (0.05, 2.0)]       # a closed-ish blob profile (radius, height)
+TEX_CAMERA = dict(view=(-14, 3, 7), eye=(1, -0.1, -0.3), left=(0, -1, 0), dist=10, hor=9.6, ver=7.2, res=40, depth=3)
+
+
+def build_textured(gpu=True, oracle=True, bsp=True, light="point_area"):
+    """every texture path of Object.h on one stage: textured + bump-mapped planes (Layout.h:76-87), textured and
+    bump-mapped spheres (Layout.h:171-175), a textured bump-mapped Bezier patch (Layout.h:121-122), a textured
+    bump-mapped surface of revolution, a textured mesh from RotationalSurfaceToMesh_Texture (Layout.h:60), a plain
+    RotationalSurfaceToMesh, a textured triangle with explicit textureCoord, a bump-mapped triangle (no tangent frame,
+    Object.h:63-64) and a textured circle (default UV, Object.h:61)"""
+    P = _Pair(0.3, gpu, oracle)
+    t_floor = P.call("add_texture_image", synth_texture(96, 80, 1))
+    t_wall = P.call("add_texture_image", synth_texture(64, 64, 2))
+    t_ball = P.call("add_texture_image", synth_texture(50, 100, 3))
+    t_skin = P.call("add_texture_image", synth_texture(40, 60, 4))
+    b_floor = P.call("add_texture_image", synth_texture(48, 48, 5, "bump"))
+    b_ball = P.call("add_texture_image", synth_texture(32, 64, 6, "bump"))
+    plastic, metal, porcelain = P.mat("plastic"), P.mat("metal"), P.mat("porcelain")
+    floor = P.call("add_plane", (0, 0, 0), (0, 0, 1), mat=porcelain, colour=(255, 255, 255))
+    P.call("add_texture", floor, t_floor, 5.0); P.call("add_bump_texture", floor, b_floor, 3.0)
+    wall = P.call("add_plane", (12, 0, 0), (-1, 0, 0), mat=plastic, colour=(255, 255, 255))
+    P.call("add_texture", wall, t_wall, 2.0); P.call("add_bump_texture", wall, b_floor, 5.0)
+    side = P.call("add_plane", (0, -9, 0), (0.3, 1, 0.1), mat=plastic, colour=(255, 255, 255))      # a tilted normal: the other u0 branches
+    P.call("add_texture", side, t_wall, 7.0)
+    s1 = P.call("add_sphere", (2, 5, 1.5), 1.5, mat=plastic, colour=(255, 255, 255))
+    P.call("add_texture", s1, t_ball)
+    s2 = P.call("add_sphere", (0, 1.5, 1.2), 1.2, mat=metal, colour=(230, 200, 120))
+    P.call("add_bump_texture", s2, b_ball)
+    ctrl = (np.array(PAPER_CTRL, dtype=np.float64) * 0.3).tolist()
+    paper = P.call("add_bezier", ctrl, (9, -3, 4), mat=P.mat("rubber"), colour=(255, 255, 255))
+    P.call("add_texture", paper, t_skin); P.call("add_bump_texture", paper, b_ball)
+    cup = P.call("add_rotational", [(1.2, 0), (0.4, 1.0), (1.6, 2.0), (1.1, 3.2)], (4, -2, 0), 20, 1.0, mat=porcelain, colour=(255, 255, 255))
+    P.call("add_texture", cup, t_skin); P.call("add_bump_texture", cup, b_ball)
+    P.call("rotational_surface_to_mesh", APPLE_PROFILE, 5, 15, (1, -5, 0.9), mat=plastic, colour=(255, 255, 255), tex=t_ball)
+    P.call("rotational_surface_to_mesh", APPLE_PROFILE, 4, 9, (6, 4, 0.9), mat=metal, colour=(80, 160, 90))
+    tri = P.call("add_triangle_tex", [(3, 0, 0.02), (7, 0.5, 0.02), (5, 3, 2.5)], None, [(0, 0), (39, 0), (20, 59)], mat=plastic, colour=(255, 255, 255))
+    P.call("add_texture", tri, t_skin); P.call("add_bump_texture", tri, b_ball)
+    circ = P.call("add_circle", (-2, -2.5, 0.6), (0.1, 0.2, 1), 1.3, mat=plastic, colour=(10, 10, 10))
+    P.call("add_texture", circ, t_wall)
+    if bsp:
+        P.call("construct_bsp")
+    if light == "point_area":
+        P.call("add_area_light", (-10, 12, 20), 1.2, 0.0, 1)
+    elif light == "area":
+        P.call("add_area_light", (-10, 12, 20), 1.2, 4.0, 2)
     return P.g, P.o

@@ -354,7 +354,7 @@ def test_c5_wine_image_parity(ctx):
 
 
 # ---- progressive photon mapping ------------------------------------------------------------------------
-def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp):
+def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp, texel_flips=0.0):
     import oracle_bind as ob
     import ray_tracing_amd as rta
     cam = rta.Camera(**cam_args)
@@ -367,7 +367,9 @@ def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp):
     assert np.abs(gh[:, 2:9] - oh[:, 2:9]).max() < 1e-6
     pic_g, pic_o = gm.picture(), om.picture()
     d0 = np.abs(pic_g - pic_o)
-    assert d0.max() <= 1 and (d0 > 0).mean() < 1e-3          # uchar truncation of doubles that agree to ~1e-13
+    # uchar truncation of doubles that agree to ~1e-13; textured scenes: plus the pixels whose hit lies on a texel boundary
+    print("%s eye pass: pixels off by one %d, by more %d of %d" % (what, int((d0.max(axis=1) == 1).sum()), int((d0.max(axis=1) > 1).sum()), d0.shape[0]))
+    assert (d0.max(axis=1) > 1).mean() <= texel_flips and (d0 > 0).mean() < 1e-3 + texel_flips
     for t in range(times):
         gm.run_pass(t)
         om.run_pass(t)
@@ -389,7 +391,7 @@ def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp):
     print("%s: picture max |diff| %d, pixels differing %d of %d, mean added %.2f" % (what, d.max(), int((d.max(axis=1) > 0).sum()), d.shape[0],
                                                                              (pic_o.sum() - 0) / pic_o.size))
     # Vec3b(tau) truncates: a tau within rounding noise of an integer may land on either side, once per pass and hit point
-    assert d.max() <= times and (d.max(axis=1) > 0).mean() < 5e-3
+    assert (d.max(axis=1) > times).mean() <= texel_flips and (d.max(axis=1) > 0).mean() < 5e-3 + texel_flips
     return gm, om
 
 
