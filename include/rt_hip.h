@@ -268,6 +268,14 @@ int rt_hip_ppm_resolve(rt_hip_ppm *ppm, double *rgb);
 int rt_hip_ppm_resolve_dev(rt_hip_ppm *ppm, double *d_rgb, void *stream);
 int rt_hip_ppm_hitpoints(rt_hip_ppm *ppm, double *out /* 11 doubles each: pixel, path, pt[3], norm[3], wgt, R, N */);
 int rt_hip_ppm_end(rt_hip_ppm *ppm);
+/* Checkpoint / resume of a long run (the reference keeps its 64 passes in one process, Camera.h:309): the state the
+ * passes change -- R and N per hit point (PhotonMapper.h:369-373), the sums added to the picture (:363-367), the
+ * photon census, the index of the next pass.  Resume = rt_hip_ppm_begin with the same scene, camera, params,
+ * photon_num and times (the eye pass is deterministic) + load_state, then passes next_pass, next_pass + 1, ...
+ * A state from a different run is refused. */
+int rt_hip_ppm_state_size(rt_hip_ppm *ppm, uint64_t *bytes);
+int rt_hip_ppm_save_state(rt_hip_ppm *ppm, void *buf, uint64_t bytes);
+int rt_hip_ppm_load_state(rt_hip_ppm *ppm, const void *buf, uint64_t bytes, uint32_t *next_pass);
 
 /* ---- god ray: CGodRay (GodRay.h:109-245) driven as in CCamera::Render_RayTracer_GodRay (Camera.h:425-448).
  * create = CGodRay(scene, lightColour); add_area_xz = AddAreaLightSource_XZ (:193-200); build = PhotonMappingPass

@@ -135,6 +135,7 @@ host.rth_render_focusing.argtypes = [_vp, _vp, _vp, C.c_double, d3, C.c_uint]
 host.rth_render_raytracer_antialiasing.argtypes = [_vp, _vp, _vp, d3, C.c_uint]
 host.rth_render_focusing_antialiasing.argtypes = [_vp, _vp, _vp, C.c_double, d3, C.c_uint, C.c_uint]
 host.rth_camera_edge_mask.argtypes = [_vp]
+host.rth_render_photon_mapper.argtypes = [_vp, _vp, _vp, C.c_int, d3, C.c_uint, C.c_char_p, C.c_char_p]
 host.rth_camera_edge_mask.restype = C.POINTER(C.c_uint8)
 host.rth_camera_rgb.argtypes = [_vp]
 host.rth_camera_prim_id.argtypes = [_vp]
@@ -154,6 +155,9 @@ hip.rt_hip_render_focusing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINT
 hip.rt_hip_render_antialiasing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.POINTER(AaParams), _vp, _vp]
 hip.rt_hip_render_antialiasing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.POINTER(AaParams), _vp, _vp, _vp]
 hip.rt_hip_last_aa_edges.argtypes = [_vp, C.POINTER(C.c_uint64)]
+hip.rt_hip_ppm_state_size.argtypes = [_vp, C.POINTER(C.c_uint64)]
+hip.rt_hip_ppm_save_state.argtypes = [_vp, _vp, C.c_uint64]
+hip.rt_hip_ppm_load_state.argtypes = [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint32)]
 hip.rt_hip_godray_create.argtypes = [_vp, d3, C.c_uint64, C.POINTER(_vp)]
 hip.rt_hip_godray_add_area_xz.argtypes = [_vp, C.c_double, C.c_double * 2, C.c_double * 2, C.c_double, d3]
 hip.rt_hip_godray_build.argtypes = [_vp]
@@ -304,6 +308,21 @@ class PhotonMap:
         out = np.zeros((self.width * self.height, 3))
         check(hip.rt_hip_ppm_resolve(self.raw, out.ctypes.data))
         return out
+
+    def save_state(self):
+        """checkpoint: bytes holding what the passes change (R, N per hit point, picture sums, census, next pass)"""
+        n = C.c_uint64()
+        check(hip.rt_hip_ppm_state_size(self.raw, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        check(hip.rt_hip_ppm_save_state(self.raw, buf.ctypes.data, n.value))
+        return buf.tobytes()
+
+    def load_state(self, state):
+        """resume: returns the index of the next pass; refuses a state of a different run"""
+        buf = np.frombuffer(state, dtype=np.uint8)
+        nxt = C.c_uint32()
+        check(hip.rt_hip_ppm_load_state(self.raw, buf.ctypes.data, buf.size, C.byref(nxt)))
+        return nxt.value
 
     def hitpoints(self):
         """(n, 11): pixel, path, pt[3], norm[3], wgt, R, N sorted by (pixel, path)"""
@@ -538,6 +557,12 @@ class Camera:
     def render_focusing_antialiasing(self, ctx, scene, radius, background=(0, 0, 0), spp=100, oversample_times=100):
         """CCamera::Render_Focusing_Antialiasing, Camera.h:201-280"""
         _chk_host(host.rth_render_focusing_antialiasing(self._h, ctx._h, scene._h, radius, d3(*background), spp, oversample_times))
+
+    def render_photon_mapper(self, ctx, scene, times, background=(0, 0, 0), photon_num=50000, checkpoint=None, progress=None):
+        """CCamera::Render_PhotonMapper, Camera.h:291-313; checkpoint / progress: optional files (state after every pass /
+        the picture after every pass as binary PPM)"""
+        _chk_host(host.rth_render_photon_mapper(self._h, ctx._h, scene._h, times, d3(*background), photon_num,
+                                                os.fsencode(checkpoint) if checkpoint else None, os.fsencode(progress) if progress else None))
 
     def edge_mask(self):
         p = host.rth_camera_edge_mask(self._h)

@@ -584,15 +584,42 @@ class Camera {                   // CCamera, Camera.h:14-51
     to_picture();
   }
   // Render_PhotonMapper, Camera.h:291-313: eye pass, then `times` photon passes of photonNum photons per light
-  // (PhotonMapper.h:155: 50000); the picture is the reference's CV_8UC3 image
-  void Render_PhotonMapper(Context &ctx, Scene &scene, int times, Colour background = Colour(0, 0, 0), uint32_t photonNum = 50000)
+  // (PhotonMapper.h:155: 50000); the picture is the reference's CV_8UC3 image.
+  // checkpoint (optional): file that receives the run's state after every pass (written beside it, then renamed); when
+  // it exists at the start and belongs to this run, the passes it covers are skipped.  progress (optional): binary PPM
+  // rewritten with the picture after every pass (the reference shows the picture once, at the end, Camera.h:310-312).
+  void Render_PhotonMapper(Context &ctx, Scene &scene, int times, Colour background = Colour(0, 0, 0), uint32_t photonNum = 50000,
+                           const std::string &checkpoint = "", const std::string &progress = "")
   {
     rt_hip_params p = params(background);
     rt_hip_ppm *m = nullptr;
     check(rt_hip_ppm_begin(scene.Device(ctx), &cam_, &p, photonNum, (uint32_t)times, &m), "rt_hip_ppm_begin");
     int rc = 0;
-    for (int t = 0; t < times && !rc; t++) rc = rt_hip_ppm_pass(m, (uint32_t)t);
+    uint32_t first = 0;
+    std::vector<unsigned char> state;
+    if (!checkpoint.empty()) {
+      uint64_t nb = 0; rc = rt_hip_ppm_state_size(m, &nb); state.resize((size_t)nb);
+      if (FILE *f = std::fopen(checkpoint.c_str(), "rb")) {
+        std::vector<unsigned char> old(state.size());
+        const bool whole = std::fread(old.data(), 1, old.size(), f) == old.size();
+        std::fclose(f);
+        if (whole && rt_hip_ppm_load_state(m, old.data(), old.size(), &first) != 0) first = 0;     // another run's file: start over
+      }
+    }
     rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.clear();
+    for (uint32_t t = first; t < (uint32_t)times && !rc; t++) {
+      rc = rt_hip_ppm_pass(m, t);
+      if (!rc && !checkpoint.empty()) {
+        rc = rt_hip_ppm_save_state(m, state.data(), state.size());
+        const std::string tmp = checkpoint + ".part";
+        FILE *f = rc ? nullptr : std::fopen(tmp.c_str(), "wb");
+        if (f) {
+          const bool ok = std::fwrite(state.data(), 1, state.size(), f) == state.size();
+          if (std::fclose(f) == 0 && ok) std::rename(tmp.c_str(), checkpoint.c_str());
+        }
+      }
+      if (!rc && !progress.empty()) { rc = rt_hip_ppm_resolve(m, rgb_.data()); if (!rc) { to_picture(); WritePPM(progress); } }
+    }
     if (!rc) rc = rt_hip_ppm_resolve(m, rgb_.data());
     rt_hip_ppm_end(m);
     check(rc, "rt_hip_ppm_pass");

@@ -136,6 +136,8 @@ int rth_render_raytracer_antialiasing(void *c, void *ctx, void *s, const double 
 { GUARD(((Camera *)c)->Render_RayTracer_Antialiasing(*(Context *)ctx, *(Scene *)s, Colour(bg[0], bg[1], bg[2]), os)) }
 int rth_render_focusing_antialiasing(void *c, void *ctx, void *s, double radius, const double bg[3], unsigned spp, unsigned os)
 { GUARD(((Camera *)c)->Render_Focusing_Antialiasing(*(Context *)ctx, *(Scene *)s, radius, Colour(bg[0], bg[1], bg[2]), spp, os)) }
+int rth_render_photon_mapper(void *c, void *ctx, void *s, int times, const double bg[3], unsigned photon_num, const char *checkpoint, const char *progress)
+{ GUARD(((Camera *)c)->Render_PhotonMapper(*(Context *)ctx, *(Scene *)s, times, Colour(bg[0], bg[1], bg[2]), photon_num, checkpoint ? checkpoint : "", progress ? progress : "")) }
 const uint8_t *rth_camera_edge_mask(void *c) { return ((Camera *)c)->edge_mask().empty() ? nullptr : ((Camera *)c)->edge_mask().data(); }
 const double *rth_camera_rgb(void *c) { return ((Camera *)c)->rgb().data(); }
 const int32_t *rth_camera_prim_id(void *c) { return ((Camera *)c)->prim_id().empty() ? nullptr : ((Camera *)c)->prim_id().data(); }

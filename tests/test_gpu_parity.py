@@ -471,3 +471,47 @@ def test_godray_room(ctx):
                                                                                          (rgb_ref - plain).max(), err.max()))
     assert lit.mean() > 0.05
     assert err.max() < 1e-3
+
+
+def test_ppm_checkpoint_resume(ctx, tmp_path):
+    """a run interrupted after any pass and resumed from its checkpoint ends bit-identical to the uninterrupted run;
+    a checkpoint of another run is refused; the host mirror's Render_PhotonMapper picks its file up"""
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(material="plastic", light="area3", extra_sphere=True)
+    cam_args = dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=20, depth=3)
+    cam = rta.Camera(**cam_args)
+    full = rta.PhotonMap(ctx, g, cam, photon_num=2000, times=3, background=(10, 10, 10), seed=5)
+    for t in range(3):
+        full.run_pass(t)
+    a = rta.PhotonMap(ctx, g, cam, photon_num=2000, times=3, background=(10, 10, 10), seed=5)
+    a.run_pass(0)
+    state = a.save_state()
+    del a
+    b = rta.PhotonMap(ctx, g, cam, photon_num=2000, times=3, background=(10, 10, 10), seed=5)
+    assert b.load_state(state) == 1
+    b.run_pass(1); b.run_pass(2)
+    assert (b.picture() == full.picture()).all()
+    assert (b.hitpoints() == full.hitpoints()).all()
+    assert b.info() == full.info()
+    # another run (different photon count): refused, and the map is left as it was
+    c = rta.PhotonMap(ctx, g, cam, photon_num=1000, times=3, background=(10, 10, 10), seed=5)
+    with pytest.raises(Exception):
+        c.load_state(state)
+    with pytest.raises(Exception):
+        c.load_state(b"garbage" * 10)
+    # host mirror: two passes with a checkpoint file, then a second call for three passes resumes after pass 1
+    ck, prog = str(tmp_path / "ppm.ck"), str(tmp_path / "ppm_progress.ppm")
+    cam.set_seed(5)
+    cam.render_photon_mapper(ctx, g, 3, background=(10, 10, 10), photon_num=2000)
+    straight = cam.rgb()
+    assert (straight == full.picture()).all()
+    part = rta.PhotonMap(ctx, g, cam, photon_num=2000, times=3, background=(10, 10, 10), seed=5)
+    part.run_pass(0); part.run_pass(1)
+    open(ck, "wb").write(part.save_state())
+    cam.render_photon_mapper(ctx, g, 3, background=(10, 10, 10), photon_num=2000, checkpoint=ck, progress=prog)
+    assert (cam.rgb() == straight).all()
+    hdr = open(prog, "rb").read(15)
+    assert hdr.startswith(b"P6\n%d %d\n255\n" % (cam.width, cam.height))
+    # the checkpoint now covers all three passes: nothing left to trace, same picture
+    cam.render_photon_mapper(ctx, g, 3, background=(10, 10, 10), photon_num=2000, checkpoint=ck)
+    assert (cam.rgb() == straight).all()
