@@ -100,21 +100,48 @@ RT_HD ParamHit bezier_hit(const DBezier &B, V3 o, V3 d)
 }
 
 // ---- CBezierCurve (Bezier.h:28-45) ----
+// de Casteljau on control points i .. i+deg.  Written with compile-time array indices (fully unrolled, the bounds
+// that depend on the degree are wave-uniform branches) so that the work array lives in registers: indexed
+// dynamically it went to scratch memory, and the Newton loops spent their time there.
 struct P2 { double u, v; };
 RT_HD P2 curve_pt(const DRotational &R, double t, int i, int deg)              // Point2D(t, i, deg)
 {
-  P2 q[8];
-  for (int k = 0; k <= deg; k++) { q[k].u = R.prof[i + k][0]; q[k].v = R.prof[i + k][1]; }
-  for (int lev = 1; lev <= deg; lev++)
-    for (int k = 0; k + lev <= deg; k++) { q[k].u = q[k].u * (1 - t) + q[k + 1].u * t; q[k].v = q[k].v * (1 - t) + q[k + 1].v * t; }
-  return q[0];
+  double qu[8], qv[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const int src = (i + k < 8) ? i + k : 7; qu[k] = R.prof[src][0]; qv[k] = R.prof[src][1]; }
+#pragma unroll
+  for (int lev = 1; lev < 8; lev++) {
+    if (lev > deg) break;
+#pragma unroll
+    for (int k = 0; k + lev < 8; k++)
+      if (k + lev <= deg) { qu[k] = qu[k] * (1 - t) + qu[k + 1] * t; qv[k] = qv[k] * (1 - t) + qv[k + 1] * t; }
+  }
+  P2 r; r.u = qu[0]; r.v = qv[0];
+  return r;
+}
+// Point2D(t) and TanVec(t) from ONE pass: the level deg-1 pair (b0, b1) of the scheme IS Point2D(t, 0, deg-1) and
+// Point2D(t, 1, deg-1) (same operations on the same control points), TanVec = (b1 - b0) * deg (Bezier.h:36-39) and
+// Point2D(t) = b0 (1-t) + b1 t (Bezier.h:33)
+RT_HD void curve_eval(const DRotational &R, double t, P2 &pt, P2 &tan)
+{
+  const int deg = R.n_prof - 1;
+  double qu[8], qv[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { qu[k] = R.prof[k][0]; qv[k] = R.prof[k][1]; }
+#pragma unroll
+  for (int lev = 1; lev < 7; lev++) {
+    if (lev > deg - 1) break;
+#pragma unroll
+    for (int k = 0; k + lev < 8; k++)
+      if (k + lev <= deg) { qu[k] = qu[k] * (1 - t) + qu[k + 1] * t; qv[k] = qv[k] * (1 - t) + qv[k + 1] * t; }
+  }
+  tan.u = (qu[1] - qu[0]) * deg; tan.v = (qv[1] - qv[0]) * deg;
+  pt.u = qu[0] * (1 - t) + qu[1] * t; pt.v = qv[0] * (1 - t) + qv[1] * t;
 }
 RT_HD P2 curve_tan(const DRotational &R, double t)                             // TanVec
 {
-  const int deg = R.n_prof - 1;
-  P2 a = curve_pt(R, t, 1, deg - 1), b = curve_pt(R, t, 0, deg - 1);
-  P2 r; r.u = (a.u - b.u) * deg; r.v = (a.v - b.v) * deg;
-  return r;
+  P2 p, tv; curve_eval(R, t, p, tv);
+  return tv;
 }
 RT_HD P2 curve_norm(const DRotational &R, double t)                            // Norm; CPoint2D::Unitize, Geometry.h:219-225
 {
@@ -131,6 +158,15 @@ RT_HD V3 rot_point(const DRotational &R, double t, double th) { P2 p = curve_pt(
 RT_HD V3 rot_norm(const DRotational &R, double t, double th) { P2 r = curve_norm(R, t); return unitize(mk(r.u * cos(th), r.u * sin(th), r.v)); }
 RT_HD V3 rot_ds_dt(const DRotational &R, double t, double th) { P2 dd = curve_tan(R, t); return mk(cos(th) * dd.u, sin(th) * dd.u, dd.v); }
 RT_HD V3 rot_ds_dth(const DRotational &R, double t, double th) { P2 p = curve_pt(R, t, 0, R.n_prof - 1); return mk(-(p.u) * sin(th), p.u * cos(th), 0); }
+// S, dS/dt, dS/dtheta at once (what one Newton step needs): one curve pass, one sine, one cosine
+RT_HD void rot_eval(const DRotational &R, double t, double th, V3 &S, V3 &dSt, V3 &dSth)
+{
+  P2 p, dd; curve_eval(R, t, p, dd);
+  const double c = cos(th), s = sin(th);
+  S = mk(p.u * c, p.u * s, p.v);
+  dSt = mk(c * dd.u, s * dd.u, dd.v);
+  dSth = mk(-(p.u) * s, p.u * c, 0);
+}
 
 // CBoundingBox::Collide == inftyPt2D (Geometry.h:302-342): the reference's own slab rule (a ray parallel to a slab is
 // never rejected by it; boxes behind the origin are accepted)
@@ -205,8 +241,8 @@ RT_HD ParamHit rotational_hit(const DRotational &R, V3 o, V3 d, bool record)
     double u = i * u_int, v, t;
     if (!rot_seed(R, u, o, d, t, v)) continue;
     for (int step = 0; step < kMaxStepNum; step++) {
-      V3 dPu = rot_ds_dt(R, u, v), dPv = rot_ds_dth(R, u, v);
-      double tp, up, vp; newton_step(d, o, center, rot_point(R, u, v), dPu, dPv, t, u, v, tp, up, vp);
+      V3 S, dPu, dPv; rot_eval(R, u, v, S, dPu, dPv);
+      double tp, up, vp; newton_step(d, o, center, S, dPu, dPv, t, u, v, tp, up, vp);
       if (up < -kMaxDeviation || up > 1 + kMaxDeviation || tp < -kMaxDeviation) break;
       if (len2(mk(tp - t, up - u, vp - v)) < kMinStepLen && tp > t_thr && 0 < up && up < R.u_range) {
         have = true;

@@ -11,6 +11,11 @@ import scenes
 
 ctx = rta.Context(0)
 dev = torch.device("cuda", 0)
+ONLY = set(a.upper() for a in sys.argv[1:])          # e.g. "C5" "C4": run only those
+
+
+def want(name):
+    return not ONLY or name in ONLY
 
 
 def ray_count(raw):
@@ -29,55 +34,59 @@ def timed(fn, reps):
 
 
 # ---- C1: icosahedron 640x480, metal, depth 3 ----
-g, _ = scenes.build_icosahedron(material="metal", light="point_area", oracle=False)
-cam = rta.Camera(**dict(scenes.C1_CAMERA, depth=3))
-n = cam.width * cam.height
-rgb = torch.zeros(n * 3, dtype=torch.float64, device=dev)
-p = rta.Params(background=(200, 200, 200))
-raw = g.device(ctx)
-dt = timed(lambda: rta.check(rta.hip.rt_hip_render_whitted_dev(raw, cam.raw, p, rgb.data_ptr(), None, None)), 20)
-rays, sh = ray_count(raw)
-print(json.dumps({"config": "C1 icosahedron 640x480 metal depth 3", "s_per_frame": round(dt, 6), "rays": rays, "Mrays_per_s": round(rays / dt / 1e6, 1)}), flush=True)
+if want("C1"):
+    g, _ = scenes.build_icosahedron(material="metal", light="point_area", oracle=False)
+    cam = rta.Camera(**dict(scenes.C1_CAMERA, depth=3))
+    n = cam.width * cam.height
+    rgb = torch.zeros(n * 3, dtype=torch.float64, device=dev)
+    p = rta.Params(background=(200, 200, 200))
+    raw = g.device(ctx)
+    dt = timed(lambda: rta.check(rta.hip.rt_hip_render_whitted_dev(raw, cam.raw, p, rgb.data_ptr(), None, None)), 20)
+    rays, sh = ray_count(raw)
+    print(json.dumps({"config": "C1 icosahedron 640x480 metal depth 3", "s_per_frame": round(dt, 6), "rays": rays, "Mrays_per_s": round(rays / dt / 1e6, 1)}), flush=True)
 
 # ---- C3: depth of field, 1080p, area light 10x10 (100 shadow rays per camera sample) ----
-g, _ = scenes.build_icosahedron(material="plastic", light="area10", oracle=False)
-cam = rta.Camera(view=(-10, 0, 1.5), eye=(1, 0, 0), left=(0, -1, 0), dist=10, hor=6, ver=3.375, res=320, depth=1)
-n = cam.width * cam.height
-rgb = torch.zeros(n * 3, dtype=torch.float64, device=dev)
-spp_run = 4
-p = rta.Params(background=(200, 200, 200), spp=1024, lens_radius=0.1, sample_first=0, sample_count=spp_run, seed=1)
-raw = g.device(ctx)
-dt = timed(lambda: rta.check(rta.hip.rt_hip_render_focusing_dev(raw, cam.raw, p, rgb.data_ptr(), None)), 2)
-rays, sh = ray_count(raw)
-print(json.dumps({"config": "C3 depth of field %dx%d, area light 10x10" % (cam.width, cam.height), "samples_timed": spp_run, "s_per_sample_pass": round(dt / spp_run, 5),
-                  "s_per_frame_at_1024spp_extrapolated": round(dt / spp_run * 1024, 1), "rays": rays, "Mrays_per_s": round(rays / dt / 1e6, 1)}), flush=True)
+if want("C3"):
+    g, _ = scenes.build_icosahedron(material="plastic", light="area10", oracle=False)
+    cam = rta.Camera(view=(-10, 0, 1.5), eye=(1, 0, 0), left=(0, -1, 0), dist=10, hor=6, ver=3.375, res=320, depth=1)
+    n = cam.width * cam.height
+    rgb = torch.zeros(n * 3, dtype=torch.float64, device=dev)
+    spp_run = 4
+    p = rta.Params(background=(200, 200, 200), spp=1024, lens_radius=0.1, sample_first=0, sample_count=spp_run, seed=1)
+    raw = g.device(ctx)
+    dt = timed(lambda: rta.check(rta.hip.rt_hip_render_focusing_dev(raw, cam.raw, p, rgb.data_ptr(), None)), 2)
+    rays, sh = ray_count(raw)
+    print(json.dumps({"config": "C3 depth of field %dx%d, area light 10x10" % (cam.width, cam.height), "samples_timed": spp_run, "s_per_sample_pass": round(dt / spp_run, 5),
+                      "s_per_frame_at_1024spp_extrapolated": round(dt / spp_run * 1024, 1), "rays": rays, "Mrays_per_s": round(rays / dt / 1e6, 1)}), flush=True)
 
 # ---- C4: wall + Bezier patch + mesh, 1080p, depth 2, one sample per pixel (the 256-spp AA driver is SURVEY 8f N2) ----
-g, _ = scenes.build_paper(oracle=False)
-cam = rta.Camera(**scenes.C4_CAMERA)
-n = cam.width * cam.height
-rgb = torch.zeros(n * 3, dtype=torch.float64, device=dev)
-p = rta.Params(background=(30, 30, 30))
-raw = g.device(ctx)
-dt = timed(lambda: rta.check(rta.hip.rt_hip_render_whitted_dev(raw, cam.raw, p, rgb.data_ptr(), None, None)), 2)
-rays, sh = ray_count(raw)
-print(json.dumps({"config": "C4 Bezier patch scene %dx%d depth 2, 1 spp" % (cam.width, cam.height), "s_per_frame": round(dt, 4), "rays": rays,
-                  "Mrays_per_s": round(rays / dt / 1e6, 1), "s_per_frame_at_256spp_extrapolated": round(dt * 256, 1)}), flush=True)
+if want("C4"):
+    g, _ = scenes.build_paper(oracle=False)
+    cam = rta.Camera(**scenes.C4_CAMERA)
+    n = cam.width * cam.height
+    rgb = torch.zeros(n * 3, dtype=torch.float64, device=dev)
+    p = rta.Params(background=(30, 30, 30))
+    raw = g.device(ctx)
+    dt = timed(lambda: rta.check(rta.hip.rt_hip_render_whitted_dev(raw, cam.raw, p, rgb.data_ptr(), None, None)), 2)
+    rays, sh = ray_count(raw)
+    print(json.dumps({"config": "C4 Bezier patch scene %dx%d depth 2, 1 spp" % (cam.width, cam.height), "s_per_frame": round(dt, 4), "rays": rays,
+                      "Mrays_per_s": round(rays / dt / 1e6, 1), "s_per_frame_at_256spp_extrapolated": round(dt * 256, 1)}), flush=True)
 
 # ---- C5: wine scene (three cups, no tree), 1080p depth 8, photon mapping ----
-g, _ = scenes.build_wine(oracle=False, cups=((-2, -2, 0), (2.2, 2.2, 0), (5, 5, 0)), light="area")
-cam = rta.Camera(**scenes.C5_CAMERA)
-t = time.perf_counter()
-photon_num = 40000          # x 4 light samples = 160,000 photons per pass here (BASELINE: 10 M per pass)
-pm = rta.PhotonMap(ctx, g, cam, photon_num=photon_num, times=64, background=(10, 10, 10), seed=1)
-torch.cuda.synchronize()
-t_eye = time.perf_counter() - t
-info = pm.info()
-t = time.perf_counter()
-pm.run_pass(0)
-t_pass = time.perf_counter() - t
-i2 = pm.info()
-print(json.dumps({"config": "C5 wine scene %dx%d depth 8, photon mapping" % (cam.width, cam.height), "eye_pass_s": round(t_eye, 3), "hit_points": info["hitpoints"],
-                  "photons_in_pass": info["photons_per_pass"], "s_per_pass": round(t_pass, 3), "photon_segments": i2["photon_segments"], "photon_hits": i2["photon_hits"],
-                  "Mphoton_segments_per_s": round(i2["photon_segments"] / t_pass / 1e6, 2),
-                  "s_per_pass_at_10M_photons_extrapolated": round(t_pass * 1e7 / info["photons_per_pass"], 1)}), flush=True)
+if want("C5"):
+    g, _ = scenes.build_wine(oracle=False, cups=((-2, -2, 0), (2.2, 2.2, 0), (5, 5, 0)), light="area")
+    cam = rta.Camera(**scenes.C5_CAMERA)
+    t = time.perf_counter()
+    photon_num = 40000          # x 4 light samples = 160,000 photons per pass here (BASELINE: 10 M per pass)
+    pm = rta.PhotonMap(ctx, g, cam, photon_num=photon_num, times=64, background=(10, 10, 10), seed=1)
+    torch.cuda.synchronize()
+    t_eye = time.perf_counter() - t
+    info = pm.info()
+    t = time.perf_counter()
+    pm.run_pass(0)
+    t_pass = time.perf_counter() - t
+    i2 = pm.info()
+    print(json.dumps({"config": "C5 wine scene %dx%d depth 8, photon mapping" % (cam.width, cam.height), "eye_pass_s": round(t_eye, 3), "hit_points": info["hitpoints"],
+                      "photons_in_pass": info["photons_per_pass"], "s_per_pass": round(t_pass, 3), "photon_segments": i2["photon_segments"], "photon_hits": i2["photon_hits"],
+                      "Mphoton_segments_per_s": round(i2["photon_segments"] / t_pass / 1e6, 2),
+                      "s_per_pass_at_10M_photons_extrapolated": round(t_pass * 1e7 / info["photons_per_pass"], 1)}), flush=True)
