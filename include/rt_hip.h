@@ -236,7 +236,8 @@ typedef struct {
   uint32_t struct_size;
   uint32_t oversample_times;        /* 0 -> 100 */
   double   r0;                      /* 0 -> 0.007 */
-  double   depth_grad_threshold;    /* 0 -> 0.8 */
+  double   depth_grad_threshold;    /* 0 -> 0.8; a negative threshold is always exceeded: every pixel is re-sampled
+                                     * (the fixed-spp jittered render of BASELINE config C4) */
   double   norm_grad_threshold;     /* 0 -> 0.8 */
   double   type_grad_threshold;     /* 0 -> 0.5 */
   double   colour_grad_threshold;   /* 0 -> 80; not used when focusing (Camera.h:258-262) */

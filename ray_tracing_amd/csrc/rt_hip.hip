@@ -318,6 +318,9 @@ int upload(rt_hip_scene *s, const std::vector<T> &v, const T **out)
 #define RT_MINWAVES 4   /* __launch_bounds__ second argument: 4 waves per SIMD = a 128-VGPR budget (no spills at 125) */
 #endif
 #define RT_WAVES (RT_BLOCK / 64)
+#ifndef RT_PARAM_MINWAVES
+#define RT_PARAM_MINWAVES 1   /* kernels with the Newton solvers compiled in: one wave per SIMD, 512 registers per lane (2 waves spill 130-380 registers) */
+#endif
 
 // diagnostic only (collect_stats builds of the kernels): start/end wall-clock stamp of every wave
 #define RT_MAX_STAMPS 65536
@@ -384,7 +387,7 @@ __device__ __forceinline__ unsigned int xcd_remap(unsigned int b, unsigned int n
 
 // rt_hip_trace_closest: CScene::FirstInterPt_BSPTree / FirstInterPt for a list of rays
 template <bool STATS, bool PARAM>
-__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_trace_closest(DevScene sc, const rt_hip_ray *rays, size_t n, rt_hip_hit *hits, Stats *gstats, int record)
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_trace_closest(DevScene sc, const rt_hip_ray *rays, size_t n, rt_hip_hit *hits, Stats *gstats, int record)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
@@ -406,7 +409,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_trace_clo
 }
 
 template <bool STATS, bool PARAM>
-__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_trace_occluded(DevScene sc, const rt_hip_ray *rays, const double *ref_pts, size_t n,
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_trace_occluded(DevScene sc, const rt_hip_ray *rays, const double *ref_pts, size_t n,
                                                               uint8_t *occluded, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
@@ -511,7 +514,7 @@ __global__ void __launch_bounds__(1024) k_order(const unsigned char *flags, unsi
 
 // level 0: camera / lens ray generation (Camera.h:65-67, 189-190) + closest hit, one 8x8 pixel tile per wave
 template <bool STATS, bool PARAM>
-__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_primary(DevScene sc, RenderArgs A, PathNode *nodes, const unsigned int *order,
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_primary(DevScene sc, RenderArgs A, PathNode *nodes, const unsigned int *order,
                                                                     unsigned char *shadow_flags, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
@@ -589,7 +592,7 @@ __device__ __forceinline__ uint64_t node_of_pixel(const RenderArgs &A, uint64_t 
 
 // levels >= 1: closest hit for queued secondary rays
 template <bool STATS, bool PARAM>
-__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n, Stats *gstats)
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
@@ -608,7 +611,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_trace_nod
 // Shadow pass: luminosity of every light at every hit node (Scene.h:104-109), one wave-packet
 // occlusion walk per light sample.  Kept apart from k_shade so that the walk runs at full occupancy.
 template <bool STATS, bool PARAM>
-__global__ void __launch_bounds__(RT_BLOCK, PARAM ? 1 : RT_MINWAVES) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n, double *lum,
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n, double *lum,
                                                       const unsigned int *order, RenderCounters *cnt, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];

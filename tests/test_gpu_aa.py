@@ -103,3 +103,19 @@ def test_antialiasing_pixel_shards_reassemble(ctx):
     # sample shards are refused
     bad = rta.Params(sample_first=0, sample_count=1)
     assert rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, bad, aa, full.ctypes.data, None) == -4
+
+
+def test_resample_every_pixel(ctx):
+    """a negative threshold is always exceeded: the driver becomes the fixed-spp jittered render (BASELINE config C4)"""
+    import ray_tracing_amd as rta
+    g, o = scenes.build_paper()
+    cam_args = dict(scenes.C4_CAMERA, hor=3.0, ver=1.7, res=16, depth=2)
+    cam = rta.Camera(**cam_args)
+    n = cam.width * cam.height
+    rgb = np.zeros((n, 3)); mask = np.zeros(n, dtype=np.uint8)
+    aa = rta.AaParams(oversample_times=8, depth_grad_threshold=-1.0)
+    rta.check(rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, rta.Params(seed=6), aa, rgb.ctypes.data, mask.ctypes.data))
+    assert mask.all()
+    rgb_ref, mask_ref = o.render_antialiasing(scenes.oracle_camera(cam_args), oversample_times=8, thresholds=(-1.0, 0.8, 0.5, 80.0), seed=6)
+    assert mask_ref.all()
+    assert _rel_err(rgb, rgb_ref).max() < 1e-3
