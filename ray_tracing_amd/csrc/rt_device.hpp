@@ -100,6 +100,10 @@ constexpr double kBoxPad = 1e-7;   // spatial inflation of node boxes (covers sl
 constexpr double kGMin = 1e-5;     // |d.n| below this: skip the cull, go to the confirm step
 
 #define RT_STACK_DEPTH 64
+#ifndef RT_BLOCK
+#define RT_BLOCK 64
+#endif
+#define RT_WAVES_DEV (RT_BLOCK / 64)
 
 // per-wave LDS: the node stack and the staged leaf chunk
 struct RayLds { double o[3], d[3], bound, pad; };    // 64 B: what a lane needs to cull a record for ANOTHER lane's ray
@@ -531,6 +535,53 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
   RT_TM_FLUSH
 }
 
+// ---- scenes without a tree: (ray, object) pairs for the surfaces of revolution ------------------------------------
+// A surface of revolution costs up to (uSampleNum + 1) x 10 Newton steps per ray that passes its box test, nothing
+// for a ray that does not.  Run per object with all lanes in lock step, a wave pays the full price whenever ANY of
+// its rays passes.  Here the rays that pass are queued as (owner lane, object) pairs, over consecutive objects,
+// and solved 64 pairs at a time with every lane busy: the solving lane gathers the owner's ray from LDS, the owner
+// folds the results in object order, so the candidate order of Scene.h:65-81 is unchanged.
+struct PairQueue {
+  unsigned short owner[128];        // lane that owns the ray
+  int obj[128];                     // object id
+  double t[64], u[64], v[64];       // results of the batch being folded
+};
+// solve the first min(n, 64) pairs; returns how many were solved.  All lanes call this together.
+__device__ __forceinline__ int pairs_solve(const DevScene &sc, WaveLds *lds, PairQueue &Q, int n, bool record)
+{
+  const int lane = threadIdx.x & 63;
+  const int nb = n < 64 ? n : 64;
+  if (lane < nb) {
+    const int src = Q.owner[lane], id = Q.obj[lane];
+    const RayLds &gr = lds->rays[src];
+    const DRotational R = sc.rotationals[sc.obj_index[id]];          // this lane's object: a private copy in registers
+    ParamHit h = rotational_solve(R, mk(gr.o[0], gr.o[1], gr.o[2]), mk(gr.d[0], gr.d[1], gr.d[2]), record);
+    Q.t[lane] = h.t; Q.u[lane] = h.u; Q.v[lane] = h.v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return nb;
+}
+__device__ __forceinline__ void pairs_shift(PairQueue &Q, int n, int done)
+{
+  // entries [done, n) move to the front (n - done < 64: one entry per lane)
+  const int lane = threadIdx.x & 63;
+  unsigned short o = 0; int b = 0;
+  if (done + lane < n) { o = Q.owner[done + lane]; b = Q.obj[done + lane]; }
+  __builtin_amdgcn_wave_barrier();
+  if (done + lane < n) { Q.owner[lane] = o; Q.obj[lane] = b; }
+  __builtin_amdgcn_wave_barrier();
+}
+// append this object's interested lanes; returns the new count (< 128)
+__device__ __forceinline__ int pairs_push(PairQueue &Q, int n, bool want, int id)
+{
+  const unsigned long long m = __ballot(want);
+  const unsigned int lane = threadIdx.x & 63;
+  const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+  if (want) { Q.owner[n + rank] = (unsigned short)lane; Q.obj[n + rank] = id; }
+  __builtin_amdgcn_wave_barrier();
+  return n + __popcll(m);
+}
+
 // Closest hit of one ray per lane (CScene::FirstInterPt_BSPTree, Scene.h:85-91; FirstInterPt, Scene.h:62-83,
 // when the scene has no tree).  Result in r.best_t / r.best_id.  All lanes of the wave call this together.
 template <bool STATS, bool PARAM>
@@ -540,6 +591,41 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
     if (t < kMiss && (r.best_id < 0 || t < r.best_t - kEps)) { r.best_t = t; r.best_id = id; if (PARAM) { r.best_u = hu; r.best_v = hv; } }
   };
   if (!sc.has_tree) {
+    if constexpr (PARAM) {
+      __shared__ PairQueue s_q[RT_WAVES_DEV];
+      PairQueue &Q = s_q[threadIdx.x >> 6];
+      const int lane = threadIdx.x & 63;
+      { RayLds &me = lds->rays[lane]; me.o[0] = r.o.x; me.o[1] = r.o.y; me.o[2] = r.o.z; me.d[0] = r.d.x; me.d[1] = r.d.y; me.d[2] = r.d.z; }
+      __builtin_amdgcn_wave_barrier();
+      int nq = 0;
+      // the owners take the results of a solved batch, in queue (= object) order
+      auto fold = [&](int nb) {
+        for (int q = 0; q < nb; q++)
+          if ((int)Q.owner[q] == lane) take(Q.t[q], Q.obj[q], Q.u[q], Q.v[q]);
+        __builtin_amdgcn_wave_barrier();
+      };
+      auto drain = [&](int keep_below) {              // solve until fewer than keep_below pairs wait
+        while (nq >= keep_below && nq > 0) { const int nb = pairs_solve(sc, lds, Q, nq, record); fold(nb); pairs_shift(Q, nq, nb); nq -= nb; }
+      };
+      for (int id = 0; id < sc.n_objects; id++) {
+        const int type = uni((int)sc.obj_type[id]);
+        if (type == 5) {                              // surface of revolution: box test now (Object.h:836-838), Newton later
+          const DRotational &R = sc.rotationals[sc.obj_index[id]];
+          const bool want = active && !ref_box_miss(R.bmin, R.bmax, r.o, r.d);
+          if (STATS && active) st.exact_tests++;
+          nq = pairs_push(Q, nq, want, id);
+          drain(64);
+        } else {
+          drain(1);                                   // the candidate order is the object order: settle the queue first
+          double hu, hv;
+          double t = active ? object_hit<PARAM>(sc, id, r.o, r.d, record, hu, hv) : kMiss;
+          if (STATS && active) st.exact_tests++;
+          if (active) take(t, id, hu, hv);
+        }
+      }
+      drain(1);
+      return;
+    } else {
     for (int id = 0; id < sc.n_objects; id++) {
       double hu, hv;
       double t = active ? object_hit<PARAM>(sc, id, r.o, r.d, record, hu, hv) : kMiss;
@@ -547,6 +633,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
       if (active) take(t, id, hu, hv);
     }
     return;
+    }
   }
   // root's infinite objects (Scene.h:329-346, 369-386) first: their hit bounds the walk.  They are applied
   // AFTER the finite objects below, as in the reference's leaf loop, so that finite objects win ties.
@@ -603,6 +690,41 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
 {
   bool found = false;
   if (!sc.has_tree) {
+    if constexpr (PARAM) {
+      __shared__ PairQueue s_q[RT_WAVES_DEV];
+      PairQueue &Q = s_q[threadIdx.x >> 6];
+      const int lane = threadIdx.x & 63;
+      { RayLds &me = lds->rays[lane]; me.o[0] = r.o.x; me.o[1] = r.o.y; me.o[2] = r.o.z; me.d[0] = r.d.x; me.d[1] = r.d.y; me.d[2] = r.d.z; }
+      __builtin_amdgcn_wave_barrier();
+      int nq = 0;
+      auto fold = [&](int nb) {
+        for (int q = 0; q < nb; q++)
+          if ((int)Q.owner[q] == lane && Q.t[q] < kMiss && occludes(r.o, r.d, Q.t[q], has_ref, ref)) found = true;
+        __builtin_amdgcn_wave_barrier();
+      };
+      auto drain = [&](int keep_below) {
+        while (nq >= keep_below && nq > 0) { const int nb = pairs_solve(sc, lds, Q, nq, false); fold(nb); pairs_shift(Q, nq, nb); nq -= nb; }
+      };
+      for (int id = 0; id < sc.n_objects; id++) {
+        const bool lane_on = active && !found;
+        if (__ballot(lane_on) == 0ull) { nq = 0; break; }     // every ray is settled: what still waits in the queue is moot
+        const int type = uni((int)sc.obj_type[id]);
+        if (type == 5) {
+          const DRotational &R = sc.rotationals[sc.obj_index[id]];
+          const bool want = lane_on && !ref_box_miss(R.bmin, R.bmax, r.o, r.d);
+          if (STATS && lane_on) st.exact_tests++;
+          nq = pairs_push(Q, nq, want, id);
+          drain(64);
+        } else {
+          double hu, hv;
+          double t = lane_on ? object_hit<PARAM>(sc, id, r.o, r.d, false, hu, hv) : kMiss;
+          if (STATS && lane_on) st.exact_tests++;
+          if (lane_on && t < kMiss && occludes(r.o, r.d, t, has_ref, ref)) found = true;
+        }
+      }
+      drain(1);
+      return found;
+    } else {
     for (int id = 0; id < sc.n_objects; id++) {
       const bool lane_on = active && !found;
       if (__ballot(lane_on) == 0ull) break;
@@ -612,6 +734,7 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
       if (lane_on && t < kMiss && occludes(r.o, r.d, t, has_ref, ref)) found = true;
     }
     return found;
+    }
   }
   for (int i = 0; i < sc.n_root_objs; i++) {
     const int id = uni(sc.root_objs[i]);

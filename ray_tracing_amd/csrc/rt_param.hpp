@@ -228,10 +228,10 @@ RT_HD bool rot_seed(const DRotational &R, double u, V3 o, V3 d, double &t_out, d
 }
 
 // CRotationalObject::FirstInterPt (record = true, t' > 10 eps) / _Unrecorded (t' > 5000 eps), Object.h:834-952
-RT_HD ParamHit rotational_hit(const DRotational &R, V3 o, V3 d, bool record)
+// the seeds and Newton iterations for a ray that passed the object's box test (Object.h:843-...)
+RT_HD ParamHit rotational_solve(const DRotational &R, V3 o, V3 d, bool record)
 {
   ParamHit h; h.t = kMiss; h.u = kInfty; h.v = kInfty;
-  if (ref_box_miss(R.bmin, R.bmax, o, d)) return h;
   const V3 center = mk(R.center[0], R.center[1], R.center[2]);
   double cur_u = kInfty, cur_v = kInfty, cur_t = kInfty;
   bool have = false;
@@ -253,6 +253,11 @@ RT_HD ParamHit rotational_hit(const DRotational &R, V3 o, V3 d, bool record)
   }
   if (have) { h.t = dist(center + rot_point(R, cur_u, cur_v), o); h.u = cur_u; h.v = cur_v; }
   return h;
+}
+RT_HD ParamHit rotational_hit(const DRotational &R, V3 o, V3 d, bool record)
+{
+  if (ref_box_miss(R.bmin, R.bmax, o, d)) { ParamHit h; h.t = kMiss; h.u = kInfty; h.v = kInfty; return h; }   // Object.h:836-838
+  return rotational_solve(R, o, d, record);
 }
 
 }  // namespace rt
