@@ -7,6 +7,8 @@ on ROCm, "gloo" in the CPU tests).  The scene is replicated; a frame is split
     returns un-clamped sums of sample/spp, which add up under all-reduce(sum); min(255, .) once at the end
     equals the reference's running clamp (Colour.h:41-47) because every term is >= 0.
 
+  * photon mapping: by photons (ppm_pass_sharded): the per-hit-point sums of a pass add up under all-reduce.
+
 The arithmetic of the shards lives here (pure functions, covered by tests/test_parallel_cpu.py with two
 gloo ranks); the rendering itself is the rt_hip_* ABI.
 """
@@ -28,6 +30,41 @@ def sample_shard(spp, rank, world):
     per, extra = divmod(spp, world)
     s0 = rank * per + min(rank, extra)
     return s0, per + (1 if rank < extra else 0)
+
+
+def photon_shard(photons_per_pass, rank, world):
+    """photons [first, first + count) of rank (rt_hip_ppm_trace's photon range)"""
+    per, extra = divmod(photons_per_pass, world)
+    first = rank * per + min(rank, extra)
+    return first, per + (1 if rank < extra else 0)
+
+
+class _DeviceArray:
+    """a raw device pointer as a 1-D float64 array for torch (``__cuda_array_interface__``): no copy"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def ppm_pass_sharded(pm, pass_index, group=None, stream=None):
+    """one iteration of PhotonMappingPass (PhotonMapper.h:226-238) over the ranks of `group`: every rank holds the same
+    hit points (rt_hip_ppm_begin is deterministic), traces its own photon range, the per-hit-point sums (M, tau) are
+    all-reduced in place in the library's accumulator buffer, and every rank applies the same update"""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    info = pm.info()
+    first, count = photon_shard(info["photons_per_pass"], rank, world)
+    s = stream if stream is not None else torch.cuda.current_stream()
+    sp = C.c_void_p(s.cuda_stream)
+    if count:
+        pm.trace(pass_index, first, count, sp)
+    ptr, n = pm.accumulators()
+    if n:
+        acc = torch.as_tensor(_DeviceArray(ptr, n), device="cuda")
+        with torch.cuda.stream(s):
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    pm.update(sp)
 
 
 def gather_rows(local, height, width, channels, group=None):
