@@ -50,6 +50,29 @@ def main():
     out["ppm_picture"] = pm.picture().astype(np.uint8)
     np.savez_compressed(os.path.join(HERE, "golden_r01.npz"), **out)
     print("wrote golden_r01.npz:", {k: v.shape for k, v in out.items()})
+    more = golden_b()
+    np.savez_compressed(os.path.join(HERE, "golden_r01b.npz"), **more)
+    print("wrote golden_r01b.npz:", {k: v.shape for k, v in more.items()})
+
+
+AA_CAM = dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=20, depth=2)
+TEX_CAM = dict(scenes.TEX_CAMERA, res=10, depth=2)
+
+
+def golden_b():
+    """anti-aliasing drivers, textures, RotationalSurfaceToMesh"""
+    out = {}
+    _, o = scenes.build_icosahedron(material="metal", light="point_area", extra_sphere=True, gpu=False)
+    rgb, mask = o.render_antialiasing(scenes.oracle_camera(AA_CAM), oversample_times=8, background=(200, 200, 200), seed=3)
+    out["aa_rgb"] = rgb; out["aa_mask"] = mask
+    rgbf, maskf = o.render_antialiasing(scenes.oracle_camera(AA_CAM), focusing=True, radius=0.1, spp=3, oversample_times=4, background=(200, 200, 200), seed=3)
+    out["aa_focus_rgb"] = rgbf; out["aa_focus_mask"] = maskf
+    _, ot = scenes.build_textured(gpu=False)
+    trgb, tids = scenes.oracle_render_whitted(ot, TEX_CAM, background=(20, 30, 40), seed=1)
+    out["tex_rgb"] = trgb; out["tex_ids"] = tids.astype(np.int32)
+    tris = [t for t in (ot.get_triangle(i) for i in range(ot.num_objects)) if t is not None]
+    out["mesh_v"] = np.array([t[0] for t in tris]); out["mesh_vn"] = np.array([t[1] for t in tris])
+    return out
 
 
 if __name__ == "__main__":

@@ -42,6 +42,49 @@ def test_oracle_reproduces_golden():
     assert (pm.picture().astype(np.uint8) == G["ppm_picture"]).all()
 
 
+GB = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_r01b.npz"))
+AA_CAM = dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=20, depth=2)
+TEX_CAM = dict(scenes.TEX_CAMERA, res=10, depth=2)
+
+
+def test_oracle_reproduces_golden_aa_textures_mesh():
+    _, o = scenes.build_icosahedron(material="metal", light="point_area", extra_sphere=True, gpu=False)
+    rgb, mask = o.render_antialiasing(scenes.oracle_camera(AA_CAM), oversample_times=8, background=(200, 200, 200), seed=3)
+    assert (mask == GB["aa_mask"]).all() and np.abs(rgb - GB["aa_rgb"]).max() < 1e-9
+    rgbf, maskf = o.render_antialiasing(scenes.oracle_camera(AA_CAM), focusing=True, radius=0.1, spp=3, oversample_times=4, background=(200, 200, 200), seed=3)
+    assert (maskf == GB["aa_focus_mask"]).all() and np.abs(rgbf - GB["aa_focus_rgb"]).max() < 1e-9
+    g, ot = scenes.build_textured()
+    trgb, tids = scenes.oracle_render_whitted(ot, TEX_CAM, background=(20, 30, 40), seed=1)
+    assert (tids == GB["tex_ids"]).all() and np.abs(trgb - GB["tex_rgb"]).max() < 1e-9
+    tg = g.triangles()                                       # host mirror's RotationalSurfaceToMesh: the golden vertices, bit for bit
+    assert (tg["v"].reshape(-1, 9) == GB["mesh_v"]).all()
+    has = tg["has_vn"] != 0
+    assert (tg["vn"].reshape(-1, 9)[has] == GB["mesh_vn"][has]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_aa_textures(ctx):
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(material="metal", light="point_area", extra_sphere=True, oracle=False)
+    cam = rta.Camera(**AA_CAM)
+    cam.set_seed(3)
+    cam.render_raytracer_antialiasing(ctx, g, background=(200, 200, 200), oversample_times=8)
+    assert (cam.edge_mask() == GB["aa_mask"]).mean() >= 1 - 1e-3
+    ok = cam.edge_mask() == GB["aa_mask"]
+    assert (np.abs(cam.rgb() - GB["aa_rgb"]) / np.maximum(1.0, np.abs(GB["aa_rgb"])))[ok].max() < 1e-3
+    cam.render_focusing_antialiasing(ctx, g, 0.1, background=(200, 200, 200), spp=3, oversample_times=4)
+    ok = cam.edge_mask() == GB["aa_focus_mask"]
+    assert ok.mean() >= 1 - 1e-3
+    assert (np.abs(cam.rgb() - GB["aa_focus_rgb"]) / np.maximum(1.0, np.abs(GB["aa_focus_rgb"])))[ok].max() < 1e-3
+    gt, _ = scenes.build_textured(oracle=False)
+    camt = rta.Camera(**TEX_CAM)
+    camt.set_seed(1)
+    camt.render_raytracer(ctx, gt, background=(20, 30, 40))
+    assert (camt.prim_id() == GB["tex_ids"]).all()
+    err = (np.abs(camt.rgb() - GB["tex_rgb"]) / np.maximum(1.0, np.abs(GB["tex_rgb"]))).max(axis=1)
+    assert (err >= 1e-3).mean() <= 1e-3                      # texel-boundary pixels
+
+
 @pytest.mark.gpu
 def test_gpu_reproduces_golden(ctx):
     import oracle_bind as ob
