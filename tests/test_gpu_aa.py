@@ -119,3 +119,27 @@ def test_resample_every_pixel(ctx):
     rgb_ref, mask_ref = o.render_antialiasing(scenes.oracle_camera(cam_args), oversample_times=8, thresholds=(-1.0, 0.8, 0.5, 80.0), seed=6)
     assert mask_ref.all()
     assert _rel_err(rgb, rgb_ref).max() < 1e-3
+
+
+def test_no_edges_and_argument_errors(ctx):
+    """thresholds out of reach: nothing is re-sampled and the frame is the plain render; bad arguments are refused"""
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(material="plastic", light="point", oracle=False)
+    cam = rta.Camera(**dict(scenes.C1_CAMERA, hor=1.6, ver=1.2, res=20, depth=1))
+    n = cam.width * cam.height
+    rgb = np.zeros((n, 3)); mask = np.ones(n, dtype=np.uint8)
+    aa = rta.AaParams(depth_grad_threshold=1e30, norm_grad_threshold=1e30, type_grad_threshold=1e30, colour_grad_threshold=1e30)
+    rta.check(rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, rta.Params(), aa, rgb.ctypes.data, mask.ctypes.data))
+    assert not mask.any()
+    cam.render_raytracer(ctx, g)
+    assert (rgb == cam.rgb()).all()
+    e = rta.C.c_uint64(7)
+    rta.check(rta.hip.rt_hip_last_aa_edges(g.device(ctx), rta.C.byref(e)))
+    assert e.value == 0
+    # NULL aa = the reference's constants; NULL frame, a wrong struct size and an absurd sample count are refused
+    rta.check(rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, rta.Params(), None, rgb.ctypes.data, None))
+    assert rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, rta.Params(), aa, None, None) == -1
+    bad = rta.AaParams(); bad.struct_size = 8
+    assert rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, rta.Params(), bad, rgb.ctypes.data, None) == -1
+    huge = rta.AaParams(oversample_times=1 << 20, focusing=1)
+    assert rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, rta.Params(spp=1 << 10), huge, rgb.ctypes.data, None) == -1
