@@ -181,6 +181,7 @@ __device__ unsigned long long g_timers[16];
 struct RayState {
   V3 o, d;
   V3 inv;             // 1/d per axis, +-1e30 for a (near) zero component so that the slab products stay finite
+  V3 oi;              // o * inv per axis: the slab test is one FMA per plane, (b * inv - oi)
   double bound;       // prune bound: nothing beyond this t can change the result
   double best_t;      // closest CONFIRMED t so far (kMiss = none)
   int best_id;
@@ -205,6 +206,7 @@ __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_
 {
   r.o = o; r.d = d;
   r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  r.oi = mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
   r.bound = kMiss; r.best_t = kMiss; r.best_id = -1;
   r.best_u = kInfty; r.best_v = kInfty; r.mb_id = -1; r.mb_t = kMiss; r.mb_u = kInfty; r.mb_v = kInfty;
   double os = dmax(dmax(fabs(o.x), fabs(o.y)), fabs(o.z));
@@ -236,13 +238,15 @@ __device__ __forceinline__ DPair load_pair(const DPair *pairs, int i)
 }
 
 // branch-free slab test against an (inflated) box: does the ray overlap it for some t in (0, bound]?
+// One FMA per plane: b * inv - (o * inv) differs from (b - o) * inv by at most |o * inv| 2^-52, i.e. it is the
+// exact test against a plane moved by |o| 2^-52 -- far inside the 1e-7 by which every box is inflated.
 __device__ __forceinline__ bool slab(const RayState &r, const double *bmin, const double *bmax)
 {
-  double t1 = (bmin[0] - r.o.x) * r.inv.x, t2 = (bmax[0] - r.o.x) * r.inv.x;
+  double t1 = fma(bmin[0], r.inv.x, -r.oi.x), t2 = fma(bmax[0], r.inv.x, -r.oi.x);
   double tmin = fmin(t1, t2), tmax = fmax(t1, t2);
-  t1 = (bmin[1] - r.o.y) * r.inv.y; t2 = (bmax[1] - r.o.y) * r.inv.y;
+  t1 = fma(bmin[1], r.inv.y, -r.oi.y); t2 = fma(bmax[1], r.inv.y, -r.oi.y);
   tmin = fmax(tmin, fmin(t1, t2)); tmax = fmin(tmax, fmax(t1, t2));
-  t1 = (bmin[2] - r.o.z) * r.inv.z; t2 = (bmax[2] - r.o.z) * r.inv.z;
+  t1 = fma(bmin[2], r.inv.z, -r.oi.z); t2 = fma(bmax[2], r.inv.z, -r.oi.z);
   tmin = fmax(tmin, fmin(t1, t2)); tmax = fmin(tmax, fmax(t1, t2));
   return (tmin <= tmax) && (tmax > 0.0) && (tmin <= r.bound);
 }

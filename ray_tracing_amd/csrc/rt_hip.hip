@@ -449,7 +449,7 @@ struct RenderArgs {
 // depend on the order.
 __device__ __forceinline__ bool ray_meets_box(V3 o, V3 d, const double *bmin, const double *bmax)
 {
-  RayState r; r.o = o; r.d = d; r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)); r.bound = kMiss;
+  RayState r; r.o = o; r.d = d; r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z)); r.oi = mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z); r.bound = kMiss;
   return slab(r, bmin, bmax);
 }
 
