@@ -1239,7 +1239,6 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   if (A.pixel_count == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
   int rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
   rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
-  RenderCounters *cnt = (RenderCounters *)s->counter.p;
   Stats *gs = stats ? s->ctx->d_stats : nullptr;
   const bool param = s->dev.has_param != 0;
   const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
