@@ -288,6 +288,62 @@ __device__ RT_OBJ_INLINE double confirm_triangle(const DevScene &sc, int prim, V
                      mk(T.nrm[0], T.nrm[1], T.nrm[2]), o, d);
 }
 
+// ---- (ray, object) pairs for the Newton-solved objects -------------------------------------------------------------
+// A surface of revolution costs up to (uSampleNum + 1) x 10 Newton steps per ray that passes its box test, a patch
+// 25 x 10, and nothing for a ray that does not meet the object.  Solved in place with all lanes in lock step, a wave
+// pays the full price whenever ANY of its rays needs the object.  Instead the rays that need one are queued as
+// (owner lane, object) pairs and solved 64 pairs at a time with every lane busy: the solving lane gathers the
+// owner's ray from LDS and works on a private copy of its object, the owner folds the results.
+// Without a tree the pairs of consecutive objects are folded in object order (the candidate order of
+// Scene.h:65-81); in the tree walk they are folded with the walk's own order-independent rule (confirmed()).
+struct PairQueue {
+  unsigned short owner[128];        // lane that owns the ray
+  int obj[128];                     // object id
+  double t[64], u[64], v[64];       // results of the batch being folded
+};
+// solve the first min(n, 64) pairs; returns how many were solved.  All lanes call this together.
+__device__ __forceinline__ int pairs_solve(const DevScene &sc, WaveLds *lds, PairQueue &Q, int n, bool record)
+{
+  const int lane = threadIdx.x & 63;
+  const int nb = n < 64 ? n : 64;
+  if (lane < nb) {
+    const int src = Q.owner[lane], id = Q.obj[lane];
+    const RayLds &gr = lds->rays[src];
+    const V3 o = mk(gr.o[0], gr.o[1], gr.o[2]), d = mk(gr.d[0], gr.d[1], gr.d[2]);
+    ParamHit h;
+    if (sc.obj_type[id] == 6) {
+      const DBezier B = sc.beziers[sc.obj_index[id]];                // this lane's object: a private copy in registers
+      h = bezier_hit(B, o, d);
+    } else {
+      const DRotational R = sc.rotationals[sc.obj_index[id]];
+      h = rotational_solve(R, o, d, record);                         // the box test was the condition for queueing
+    }
+    Q.t[lane] = h.t; Q.u[lane] = h.u; Q.v[lane] = h.v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return nb;
+}
+__device__ __forceinline__ void pairs_shift(PairQueue &Q, int n, int done)
+{
+  // entries [done, n) move to the front (n - done < 64: one entry per lane)
+  const int lane = threadIdx.x & 63;
+  unsigned short o = 0; int b = 0;
+  if (done + lane < n) { o = Q.owner[done + lane]; b = Q.obj[done + lane]; }
+  __builtin_amdgcn_wave_barrier();
+  if (done + lane < n) { Q.owner[lane] = o; Q.obj[lane] = b; }
+  __builtin_amdgcn_wave_barrier();
+}
+// append this object's interested lanes; returns the new count (< 128)
+__device__ __forceinline__ int pairs_push(PairQueue &Q, int n, bool want, int id)
+{
+  const unsigned long long m = __ballot(want);
+  const unsigned int lane = threadIdx.x & 63;
+  const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+  if (want) { Q.owner[n + rank] = (unsigned short)lane; Q.obj[n + rank] = id; }
+  __builtin_amdgcn_wave_barrier();
+  return n + __popcll(m);
+}
+
 // Deferred-confirmation state of one ray.  During the fast walk only the cull runs; the two nearest
 // cull survivors (by t') are remembered and confirmed once, after the walk, by all lanes together.
 // A lane whose survivors are not conclusive (see finish_closest / finish_any) is re-walked with the
@@ -324,6 +380,24 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
   int sp = 0;
   ChildRef cur = sc.root;
   bool have = true;                                // `cur` holds the next node (the near child); else pop
+  // Newton-solved objects met in leaves (fast walk only): queued, solved 64 pairs at a time, see PairQueue
+  __shared__ PairQueue s_pq[(PARAM && DEFER) ? RT_WAVES_DEV : 1];
+  PairQueue &PQ = s_pq[(PARAM && DEFER) ? (threadIdx.x >> 6) : 0];
+  int nq = 0;
+  auto solve_pairs = [&](int keep_below) {
+    if constexpr (PARAM && DEFER) {
+      const int lane = threadIdx.x & 63;
+      while (nq >= keep_below && nq > 0) {
+        const int nb = pairs_solve(sc, lds, PQ, nq, record);
+        const double bt = r.best_t;
+        for (int q = 0; q < nb; q++)
+          if ((int)PQ.owner[q] == lane) confirmed(PQ.t[q], PQ.obj[q], !(ANY && found), PQ.u[q], PQ.v[q]);
+        if (!ANY && r.best_t != bt) lds->rays[lane].bound = r.bound;
+        __builtin_amdgcn_wave_barrier();
+        pairs_shift(PQ, nq, nb); nq -= nb;
+      }
+    }
+  };
   if constexpr (DEFER) {                           // this wave's rays, for the redistributed cull (LDS is in order per wave)
     RayLds &me = lds->rays[threadIdx.x & 63];
     me.o[0] = r.o.x; me.o[1] = r.o.y; me.o[2] = r.o.z; me.d[0] = r.d.x; me.d[1] = r.d.y; me.d[2] = r.d.z; me.bound = r.bound; me.pad = 0.0;
@@ -455,6 +529,19 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
             const int prim = uni(recs[i].prim_id);
             const bool lane_on = want && !(ANY && found);
             if (STATS && lane_on) st.exact_tests++;
+            if constexpr (PARAM) {
+              const int type = uni((int)sc.obj_type[prim]);
+              if (type == 5 || type == 6) {
+                // the mailbox remembers the object this ray queued last: the reference re-solves an object in every
+                // leaf that lists it (Scene.h:352), always with the same result
+                bool push = lane_on && r.mb_id != prim;
+                if (push) r.mb_id = prim;
+                if (type == 5) { const DRotational &R = sc.rotationals[sc.obj_index[prim]]; push = push && !ref_box_miss(R.bmin, R.bmax, r.o, r.d); }
+                nq = pairs_push(PQ, nq, push, prim);
+                solve_pairs(64);
+                continue;
+              }
+            }
             const double bt = r.best_t;
             double hu = kInfty, hv = kInfty;
             const double ht = lane_on ? leaf_other_hit<PARAM>(sc, r, prim, record, hu, hv) : kMiss;
@@ -536,54 +623,8 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
       }
     }
   }
+  solve_pairs(1);
   RT_TM_FLUSH
-}
-
-// ---- scenes without a tree: (ray, object) pairs for the surfaces of revolution ------------------------------------
-// A surface of revolution costs up to (uSampleNum + 1) x 10 Newton steps per ray that passes its box test, nothing
-// for a ray that does not.  Run per object with all lanes in lock step, a wave pays the full price whenever ANY of
-// its rays passes.  Here the rays that pass are queued as (owner lane, object) pairs, over consecutive objects,
-// and solved 64 pairs at a time with every lane busy: the solving lane gathers the owner's ray from LDS, the owner
-// folds the results in object order, so the candidate order of Scene.h:65-81 is unchanged.
-struct PairQueue {
-  unsigned short owner[128];        // lane that owns the ray
-  int obj[128];                     // object id
-  double t[64], u[64], v[64];       // results of the batch being folded
-};
-// solve the first min(n, 64) pairs; returns how many were solved.  All lanes call this together.
-__device__ __forceinline__ int pairs_solve(const DevScene &sc, WaveLds *lds, PairQueue &Q, int n, bool record)
-{
-  const int lane = threadIdx.x & 63;
-  const int nb = n < 64 ? n : 64;
-  if (lane < nb) {
-    const int src = Q.owner[lane], id = Q.obj[lane];
-    const RayLds &gr = lds->rays[src];
-    const DRotational R = sc.rotationals[sc.obj_index[id]];          // this lane's object: a private copy in registers
-    ParamHit h = rotational_solve(R, mk(gr.o[0], gr.o[1], gr.o[2]), mk(gr.d[0], gr.d[1], gr.d[2]), record);
-    Q.t[lane] = h.t; Q.u[lane] = h.u; Q.v[lane] = h.v;
-  }
-  __builtin_amdgcn_wave_barrier();
-  return nb;
-}
-__device__ __forceinline__ void pairs_shift(PairQueue &Q, int n, int done)
-{
-  // entries [done, n) move to the front (n - done < 64: one entry per lane)
-  const int lane = threadIdx.x & 63;
-  unsigned short o = 0; int b = 0;
-  if (done + lane < n) { o = Q.owner[done + lane]; b = Q.obj[done + lane]; }
-  __builtin_amdgcn_wave_barrier();
-  if (done + lane < n) { Q.owner[lane] = o; Q.obj[lane] = b; }
-  __builtin_amdgcn_wave_barrier();
-}
-// append this object's interested lanes; returns the new count (< 128)
-__device__ __forceinline__ int pairs_push(PairQueue &Q, int n, bool want, int id)
-{
-  const unsigned long long m = __ballot(want);
-  const unsigned int lane = threadIdx.x & 63;
-  const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-  if (want) { Q.owner[n + rank] = (unsigned short)lane; Q.obj[n + rank] = id; }
-  __builtin_amdgcn_wave_barrier();
-  return n + __popcll(m);
 }
 
 // Closest hit of one ray per lane (CScene::FirstInterPt_BSPTree, Scene.h:85-91; FirstInterPt, Scene.h:62-83,
@@ -670,6 +711,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
     if (STATS) { if (redo) st.pad++; if ((threadIdx.x & 63) == 0) st.pad += (1ull << 32); }
     RayState q = r;
     q.best_t = kMiss; q.best_id = -1; q.bound = (inf_id >= 0) ? inf_t + r.tmargin : kMiss;
+    q.mb_id = -1;                            // the fast walk used the mailbox as a 'queued' mark only
     walk<false, false, STATS, PARAM>(sc, q, redo, false, mk(0, 0, 0), 0.0, lds, st, D, dummy, record);
     if (redo) { r.best_t = q.best_t; r.best_id = q.best_id; if (PARAM) { r.best_u = q.best_u; r.best_v = q.best_v; } }
   }
@@ -763,7 +805,7 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
   if (__ballot(redo) != 0ull) {
     if (STATS) { if (redo) st.pad++; if ((threadIdx.x & 63) == 0) st.pad += (1ull << 32); }
     bool f2 = false;
-    RayState q = r; q.bound = t_limit;
+    RayState q = r; q.bound = t_limit; q.mb_id = -1;
     walk<true, false, STATS, PARAM>(sc, q, redo, has_ref, ref, fmargin, lds, st, D, f2, false);
     if (redo) found = f2;
   }
