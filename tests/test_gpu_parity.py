@@ -515,3 +515,24 @@ def test_ppm_checkpoint_resume(ctx, tmp_path):
     # the checkpoint now covers all three passes: nothing left to trace, same picture
     cam.render_photon_mapper(ctx, g, 3, background=(10, 10, 10), photon_num=2000, checkpoint=ck)
     assert (cam.rgb() == straight).all()
+
+
+@pytest.mark.parametrize("hor,ver,res", [(3.1, 2.3, 33), (0.31, 0.2, 30), (2.0, 0.05, 20)])
+def test_odd_image_sizes(ctx, hor, ver, res):
+    """frames whose sides are not multiples of the 8x8 wave tile (padding lanes, partial super-tiles), down to a
+    one-row strip: Whitted, depth of field and the anti-aliasing driver against the oracle"""
+    import ray_tracing_amd as rta
+    g, o = scenes.build_icosahedron(material="metal", light="point_area", extra_sphere=True)
+    cam_args = dict(scenes.C1_CAMERA, hor=hor, ver=ver, res=res, depth=2)
+    cam = rta.Camera(**cam_args)
+    assert cam.width % 8 != 0 or cam.height % 8 != 0
+    cam.set_seed(4)
+    cam.render_raytracer(ctx, g, background=(200, 200, 200))
+    rgb_ref, ids_ref = scenes.oracle_render_whitted(o, cam_args, background=(200, 200, 200), seed=4)
+    assert (cam.prim_id() == ids_ref).all() and _rel_err(cam.rgb(), rgb_ref).max() < 1e-3
+    cam.render_focusing(ctx, g, 0.05, background=(200, 200, 200), spp=3)
+    ref = o.render_focusing(scenes.oracle_camera(cam_args), 0.05, 3, background=(200, 200, 200), seed=4)
+    assert _rel_err(cam.rgb(), ref).max() < 1e-3
+    cam.render_raytracer_antialiasing(ctx, g, background=(200, 200, 200), oversample_times=3)
+    aref, mref = o.render_antialiasing(scenes.oracle_camera(cam_args), oversample_times=3, background=(200, 200, 200), seed=4)
+    assert (cam.edge_mask() == mref).all() and _rel_err(cam.rgb(), aref).max() < 1e-3
