@@ -234,7 +234,7 @@ class Context:
         return d
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and host is not None:
             host.rth_context_free(self._h)
             self._h = None
 
@@ -270,7 +270,7 @@ class GodRay:
         return rgb, ids
 
     def __del__(self):
-        if getattr(self, "raw", None):
+        if getattr(self, "raw", None) and hip is not None:
             hip.rt_hip_godray_destroy(self.raw)
             self.raw = None
 
@@ -334,7 +334,7 @@ class PhotonMap:
         return out
 
     def __del__(self):
-        if getattr(self, "raw", None):
+        if getattr(self, "raw", None) and hip is not None:
             hip.rt_hip_ppm_end(self.raw)
             self.raw = None
 
@@ -348,7 +348,7 @@ class SharedScene:
         check(hip.rt_hip_scene_share(parent.device(ctx), C.byref(self.raw)))
 
     def __del__(self):
-        if getattr(self, "raw", None):
+        if getattr(self, "raw", None) and hip is not None:
             hip.rt_hip_scene_destroy(self.raw)
             self.raw = None
 
@@ -522,7 +522,7 @@ class Scene:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and host is not None:
             host.rth_scene_free(self._h)
             self._h = None
 
@@ -583,6 +583,6 @@ class Camera:
         _chk_host(host.rth_camera_write_ppm(self._h, os.fsencode(path)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and host is not None:
             host.rth_camera_free(self._h)
             self._h = None

@@ -193,6 +193,8 @@ def build_wine(gpu=True, oracle=True, cups=((-2, -2, 0),), light="point", cup_ma
         P.call("add_point_light", (-10, 25, 25), 2.0)
     elif light == "area":
         P.call("add_area_light", (-10, 25, 25), 2.0, 2.0, 2)
+    elif light == "area5":                     # AddAreaLight((-10,25,25), 2, 2, 5)
+        P.call("add_area_light", (-10, 25, 25), 2.0, 2.0, 5)
     return P.g, P.o
 
 
