@@ -479,37 +479,42 @@ __global__ void __launch_bounds__(256) k_classify(DevScene sc, RenderArgs A, uns
   flags[w] = heavy ? 1 : 0;
 }
 
-// single block: stable partition of the wave indices by flag, 1024 indices per step (ballot + 16 wave totals)
-__global__ void __launch_bounds__(1024) k_order(const unsigned char *flags, unsigned int n, unsigned int *order)
+// stable partition of the wave indices by flag, 1024 indices per block, two small launches:
+//   k_order_count  : heavy entries per block
+//   k_order        : every block sums the counts of the blocks before it (a few dozen numbers), then places its own
+//                    entries -- heavy ones from its heavy base, light ones after ALL heavy ones from its light base
+__global__ void __launch_bounds__(1024) k_order_count(const unsigned char *flags, unsigned int n, unsigned int *counts)
 {
   __shared__ unsigned int s_w[16];
   const unsigned int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const unsigned int i = blockIdx.x * 1024 + t;
+  const unsigned long long mask = __ballot(i < n && flags[i]);
+  if (lane == 0) s_w[w] = (unsigned int)__popcll(mask);
+  __syncthreads();
+  if (t == 0) { unsigned int c = 0; for (int k = 0; k < 16; k++) c += s_w[k]; counts[blockIdx.x] = c; }
+}
+__global__ void __launch_bounds__(1024) k_order(const unsigned char *flags, unsigned int n, const unsigned int *counts, unsigned int *order)
+{
+  __shared__ unsigned int s_w[16];
+  __shared__ unsigned int s_base[2];
+  const unsigned int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  // heavy total
-  unsigned int c = 0;
-  for (unsigned int i = t; i < n; i += 1024) c += flags[i] ? 1u : 0u;
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  if (lane == 0) s_w[w] = c;
-  __syncthreads();
-  unsigned int total = 0;
-  for (int k = 0; k < 16; k++) total += s_w[k];
-  __syncthreads();
-  unsigned int hbase = 0, lbase = total;
-  for (unsigned int base = 0; base < n; base += 1024) {
-    const unsigned int i = base + t;
-    const bool valid = i < n;
-    const bool f = valid && flags[i];
-    const unsigned long long mask = __ballot(f);
-    if (lane == 0) s_w[w] = (unsigned int)__popcll(mask);
-    __syncthreads();
-    unsigned int before = 0, tile_total = 0;
-    for (unsigned int k = 0; k < 16; k++) { const unsigned int v = s_w[k]; if (k < w) before += v; tile_total += v; }
-    __syncthreads();
-    const unsigned int hrank = before + (unsigned int)__popcll(mask & below);     // heavy entries of this step before me
-    if (valid) order[f ? (hbase + hrank) : (lbase + (t - hrank))] = i;
-    const unsigned int in_tile = (n - base < 1024u) ? (n - base) : 1024u;
-    hbase += tile_total; lbase += in_tile - tile_total;
+  if (w == 0) {                                   // heavy entries before this block, and in all blocks
+    unsigned int before = 0, total = 0;
+    for (unsigned int b = lane; b < gridDim.x; b += 64) { const unsigned int c = counts[b]; total += c; if (b < blockIdx.x) before += c; }
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_down(before, off, 64); total += __shfl_down(total, off, 64); }
+    if (lane == 0) { s_base[0] = before; s_base[1] = total + (blockIdx.x * 1024u - before); }   // light base: after all heavy ones
   }
+  const unsigned int i = blockIdx.x * 1024 + t;
+  const bool valid = i < n;
+  const bool f = valid && flags[i];
+  const unsigned long long mask = __ballot(f);
+  if (lane == 0) s_w[w] = (unsigned int)__popcll(mask);
+  __syncthreads();
+  unsigned int before_w = 0;
+  for (unsigned int k = 0; k < w; k++) before_w += s_w[k];
+  const unsigned int hrank = before_w + (unsigned int)__popcll(mask & below);     // heavy entries of this block before me
+  if (valid) order[f ? (s_base[0] + hrank) : (s_base[1] + (t - hrank))] = i;
 }
 
 // level 0: camera / lens ray generation (Camera.h:65-67, 189-190) + closest hit, one 8x8 pixel tile per wave
@@ -1244,14 +1249,17 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
   PathNode *L0 = (PathNode *)s->levels[0].p;
   // heavy-first order of the level-0 waves (only worth it with a tree)
-  unsigned int *order0 = nullptr, *order1 = nullptr; unsigned char *flags0 = nullptr, *flags1 = nullptr;
+  unsigned int *order0 = nullptr, *order1 = nullptr, *ocounts = nullptr; unsigned char *flags0 = nullptr, *flags1 = nullptr;
+  unsigned int oblocks = 0;
   if (s->dev.has_tree) {
-    rc = s->order.ensure(n_waves * 10 + 64); if (rc) return rc;
-    order0 = (unsigned int *)s->order.p; order1 = order0 + n_waves;
-    flags0 = (unsigned char *)(order1 + n_waves); flags1 = flags0 + n_waves;
+    oblocks = (unsigned int)((n_waves + 1023) / 1024);
+    rc = s->order.ensure(n_waves * 10 + (size_t)oblocks * 4 + 64); if (rc) return rc;
+    order0 = (unsigned int *)s->order.p; order1 = order0 + n_waves; ocounts = order1 + n_waves;
+    flags0 = (unsigned char *)(ocounts + oblocks); flags1 = flags0 + n_waves;
     ProfScope ps(s, RT_HIP_K_ORDER, st);
     hipLaunchKernelGGL(k_classify, dim3((unsigned int)((n_waves + 255) / 256)), dim3(256), 0, st, s->dev, A, (unsigned int)n_waves, flags0);
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, order0);
+    hipLaunchKernelGGL(k_order_count, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, ocounts);
+    hipLaunchKernelGGL(k_order, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, (const unsigned int *)ocounts, order0);
   }
   {
     ProfScope ps(s, RT_HIP_K_PRIMARY, st);
@@ -1259,7 +1267,8 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   }
   if (s->dev.has_tree && s->dev.n_lights > 0) {
     ProfScope ps(s, RT_HIP_K_ORDER, st);
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const unsigned char *)flags1, (unsigned int)n_waves, order1);
+    hipLaunchKernelGGL(k_order_count, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags1, (unsigned int)n_waves, ocounts);
+    hipLaunchKernelGGL(k_order, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags1, (unsigned int)n_waves, (const unsigned int *)ocounts, order1);
   } else order1 = nullptr;
   HIP_TRY(hipGetLastError());
   return run_levels_from(s, A, stats, st, n0, order1, A.pixel_count * A.n_samples, direct_rgb, direct_id);
