@@ -1062,28 +1062,35 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
   return lum;
 }
 
-// CScene::LocalIllumination, Scene.h:93-122.  lum[li] = luminosity of
-// light li at pt, computed beforehand by the shadow pass (light_luminosity).
+// CScene::LocalIllumination, Scene.h:93-122, in two pieces so that the shadow pass can sum it light by light:
+// shade_setup = what does not depend on the light (normal, flipped normal, reflected view direction, material,
+// object colour), light_term = one light's contribution given its luminosity at pt.
+template <bool PARAM = false>
+__device__ __forceinline__ V3 shade_setup(const DevScene &sc, V3 d, int id, V3 pt, double hu, double hv, V3 &norm, V3 &refl, DMaterial &M, Col &oc)
+{
+  V3 N = object_norm<PARAM>(sc, id, pt, hu, hv);
+  norm = N;
+  if (dot(d, norm) > kEps) norm = neg(norm);
+  M = sc.materials[sc.obj_mat[id]];
+  oc = object_colour<PARAM>(sc, id, pt, hu, hv);         // Scene.h:101
+  refl = reflect_dir(N, d);
+  return N;
+}
+__device__ __forceinline__ Col light_term(const DevScene &sc, const DMaterial &M, Col oc, V3 norm, V3 refl, const DLight &L, V3 pt, double l)
+{
+  V3 ldir = (L.type == 101) ? mk(L.p[0], L.p[1], L.p[2]) : unitize(pt - mk(L.p[0], L.p[1], L.p[2]));
+  double diffuse = M.diff * dmax(0.0, -dot(norm, ldir) * l);
+  double specular = M.spec * l * pow(dmax(0.0, -dot(ldir, refl)), M.shiness);
+  return cmul(oc, M.emissive + sc.ambient * M.ambient + diffuse + specular);
+}
+// lum[li] = luminosity of light li at pt, computed beforehand by the shadow pass (light_luminosity)
 template <bool PARAM = false>
 __device__ __forceinline__ Col local_illumination(const DevScene &sc, V3 d, int id, V3 pt, const double *lum, V3 &N_out,
                                                   double hu = kInfty, double hv = kInfty)
 {
-  Col colour = mkc(0, 0, 0);
-  V3 N = object_norm<PARAM>(sc, id, pt, hu, hv);
-  N_out = N;
-  V3 norm = N;
-  if (dot(d, norm) > kEps) norm = neg(norm);
-  const DMaterial M = sc.materials[sc.obj_mat[id]];
-  const Col oc = object_colour<PARAM>(sc, id, pt, hu, hv);         // Scene.h:101
-  const V3 refl = reflect_dir(N, d);
-  for (int li = 0; li < sc.n_lights; li++) {
-    const DLight &L = sc.lights[li];
-    const double l = lum[li];
-    V3 ldir = (L.type == 101) ? mk(L.p[0], L.p[1], L.p[2]) : unitize(pt - mk(L.p[0], L.p[1], L.p[2]));
-    double diffuse = M.diff * dmax(0.0, -dot(norm, ldir) * l);
-    double specular = M.spec * l * pow(dmax(0.0, -dot(ldir, refl)), M.shiness);
-    colour = cadd(colour, cmul(oc, M.emissive + sc.ambient * M.ambient + diffuse + specular));
-  }
+  Col colour = mkc(0, 0, 0), oc; V3 norm, refl; DMaterial M;
+  N_out = shade_setup<PARAM>(sc, d, id, pt, hu, hv, norm, refl, M, oc);
+  for (int li = 0; li < sc.n_lights; li++) colour = cadd(colour, light_term(sc, M, oc, norm, refl, sc.lights[li], pt, lum[li]));
   return colour;
 }
 
