@@ -3,8 +3,9 @@
 synthetic 1,002,528-triangle heightfield + ground plane, primary + shadow ray casting at 1920x1080
 (SURVEY 8d C2), through the rt_hip_* C ABI with every input resident in HBM.
 
-A "step" = one full frame: camera-ray generation + closest hit (k_primary), one shadow query per hit
-pixel (k_shadow), shading (k_shade) and the resolve to an RGB f64 frame.  `--streams S` (default 2) keeps S
+A "step" = one full frame: camera-ray generation + closest hit, one shadow query per hit pixel, the local
+illumination and the RGB f64 frame -- for this depth-1 camera all in ONE launch (k_frame_direct; deeper ray trees
+run k_primary / k_shadow / k_shade per level).  `--streams S` (default 2) keeps S
 frames in flight per GPU, frame k on stream k % S with its own rt_hip_scene_share handle: wave costs in
 these kernels differ 50x, and the draining tail of one frame is filled by the next frame's waves.  The time
 per frame with one frame in flight is reported beside it (config.ms_per_frame_one_in_flight).
@@ -220,8 +221,11 @@ def main():
     # are per ray.  The per-lane figure (what 64 independent rays would fetch) is reported beside it.
     wave_boxes_per_ray = st["wave_node_visits"] / nrays
     wave_recs_per_ray = st["wave_prim_tests"] / nrays
-    bytes_per_ray = 48 + 32 + 64 * wave_boxes_per_ray + 128 * wave_recs_per_ray + 96 * exact_per_ray
-    lane_bytes_per_ray = 48 + 32 + 64 * nodes_per_ray + 128 * prims_per_ray + 96 * exact_per_ray
+    # k_frame_direct generates its rays and keeps the hits in registers: its only per-ray traffic is the frame
+    # (24 B colour + 4 B id per pixel = per 2 rays)
+    io_bytes = 14 if dom == "k_frame_direct" else 48 + 32
+    bytes_per_ray = io_bytes + 64 * wave_boxes_per_ray + 128 * wave_recs_per_ray + 96 * exact_per_ray
+    lane_bytes_per_ray = io_bytes + 64 * nodes_per_ray + 128 * prims_per_ray + 96 * exact_per_ray
     flops_per_ray = 40 * nodes_per_ray + 45 * prims_per_ray + 150 * exact_per_ray
     rays_dom = (rays_per_frame - shadow_pf.value) if dom == "k_primary" else shadow_pf.value if dom == "k_shadow" else rays_per_frame
     ach_gbs = bytes_per_ray * rays_dom / (dom_ms * 1e-3) / 1e9

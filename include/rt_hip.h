@@ -306,6 +306,7 @@ int rt_hip_godray_destroy(rt_hip_godray *g);
 #define RT_HIP_K_SHADOW         7   /* luminosity of every light at every hit: occlusion walks */
 #define RT_HIP_K_ORDER          8   /* heavy-first work ordering (classification + stable partition) */
 #define RT_HIP_K_AA             9   /* anti-aliasing drivers: G-buffer maps, edge mask, per-pixel sums */
+#define RT_HIP_K_FRAME_DIRECT  10   /* a depth-1 frame in one launch: camera rays, closest hit, luminosities, local illumination */
 #define RT_HIP_K_COUNT          12
 typedef struct { double ms[RT_HIP_K_COUNT]; uint64_t launches[RT_HIP_K_COUNT]; } rt_hip_profile;
 int rt_hip_set_profiling(rt_hip_scene *scene, int on);

@@ -78,7 +78,7 @@ class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 12), ("launches", C.c_uint64 * 12)]
 
 
-KERNEL_NAMES = ["k_primary", "k_trace_nodes", "k_shade", "k_combine", "k_resolve", "k_trace_closest", "k_trace_occluded", "k_shadow", "k_order", "-", "-", "-"]
+KERNEL_NAMES = ["k_primary", "k_trace_nodes", "k_shade", "k_combine", "k_resolve", "k_trace_closest", "k_trace_occluded", "k_shadow", "k_order", "k_aa", "k_frame_direct", "-"]
 
 hip.rt_hip_last_error.restype = C.c_char_p
 host.rth_last_error.restype = C.c_char_p

@@ -584,6 +584,63 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   if (STATS) stats_flush(gstats, st);
 }
 
+// A depth-1 frame in ONE launch (Camera.h:53-75 with depth == 1): camera ray + closest hit as in k_primary, the
+// luminosities as in k_shadow, the local illumination, the frame.  Nothing goes through a level array, and the
+// low-occupancy tail of the primary pass disappears into the shadow walks of the same waves.
+template <bool STATS, bool PARAM>
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_frame_direct(DevScene sc, RenderArgs A, const unsigned int *order, double *lum,
+                                                                          RenderCounters *cnt, Stats *gstats, double *rgb, int32_t *prim_id)
+{
+  __shared__ WaveLds s_lds[RT_WAVES];
+  WaveLds *stack = &s_lds[threadIdx.x >> 6];
+  const unsigned int slot = xcd_remap(blockIdx.x, gridDim.x) * RT_WAVES + (threadIdx.x >> 6);
+  const unsigned int wave = order ? (unsigned int)uni((int)order[slot]) : slot;
+  const unsigned int lane = threadIdx.x & 63;
+  unsigned int s_local, tx, ty; tile_of_wave(A, wave, s_local, tx, ty);
+  const unsigned int h = tx * 8 + (lane & 7);
+  const unsigned int v = A.v_lo + ty * 8 + (lane >> 3);
+  const uint64_t p = (uint64_t)v * A.cam.W + h;
+  const bool active = (s_local < A.n_samples) && (tx < A.tiles_x) && (ty < A.tiles_y) && (h < (unsigned)A.cam.W) && (v < (unsigned)A.cam.H) &&
+                      (p >= A.pixel_first) && (p < A.pixel_first + A.pixel_count);
+  Stats st{};
+  // Camera.h:65-67; evaluated again after the walks instead of being kept alive across them
+  auto camera_ray = [&](V3 &o, V3 &d) {
+    V3 cur = A.cam.start - A.cam.left * (double(h) / double(A.cam.res)) - A.cam.up * (double(v) / double(A.cam.res));
+    o = A.cam.view_pt;
+    d = unitize(unitize(cur - o));
+  };
+  int id; double t, hu = kInfty, hv = kInfty; V3 pt;
+  {
+    V3 o, d; camera_ray(o, d);
+    RayState r; ray_setup(r, o, d, sc.coord_scale);
+    if (STATS && active) st.rays++;
+    trace_closest<STATS, PARAM>(sc, r, active, stack, st);
+    id = r.best_id; t = r.best_t;
+    if (PARAM) { hu = r.best_u; hv = r.best_v; }
+    pt = o + d * t;
+  }
+  const bool hit = active && id >= 0;
+  if (!hit) pt = mk(0, 0, 0);
+  const size_t i = (size_t)wave * 64 + lane;
+  RngKey key; key.seed = A.seed; key.pixel = (uint32_t)p; key.sample = A.sample_first + s_local; key.path = 1;
+  unsigned long long my_shadow = 0;
+  for (int li = 0; li < sc.n_lights; li++) {
+    const DLight &L = sc.lights[li];
+    double l = light_luminosity<STATS, PARAM>(sc, L, li, pt, hit, key, stack, st);
+    if (hit) { lum[i * sc.n_lights + li] = l; my_shadow += (L.type == 102) ? (unsigned long long)L.sample_num * L.sample_num : 1ull; }
+  }
+  if (active) {
+    Col c = mkc(A.bg[0], A.bg[1], A.bg[2]);
+    if (hit) { V3 o, d, N; camera_ray(o, d); c = local_illumination<PARAM>(sc, d, id, pt, lum + i * sc.n_lights, N, hu, hv); }
+    const uint64_t q = p - A.pixel_first;
+    rgb[3 * q] = c.r; rgb[3 * q + 1] = c.g; rgb[3 * q + 2] = c.b;
+    if (prim_id) prim_id[q] = id;
+  }
+  for (int off = 32; off > 0; off >>= 1) my_shadow += __shfl_down(my_shadow, off, 64);
+  if (lane == 0 && my_shadow) atomicAdd(&cnt->shadow_rays, my_shadow);
+  if (STATS) stats_flush(gstats, st);
+}
+
 // index of the level-0 node of raster pixel p (inverse of k_primary's tile numbering)
 __device__ __forceinline__ uint64_t node_of_pixel(const RenderArgs &A, uint64_t p, uint32_t s_local)
 {
@@ -1217,7 +1274,9 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
     rc = s->lum.ensure((size_t)n * std::max(1, s->dev.n_lights) * sizeof(double)); if (rc) return rc;
     double *lum = (double *)s->lum.p;
     const bool direct = direct_rgb && lv == 0 && depth == 1;
-    const bool fused = direct && s->dev.n_lights > 0 && !s->god;      // the shadow pass shades and writes the frame itself
+    // the shadow pass shades and writes the frame itself -- unless someone reads the level array afterwards
+    // (photon mapping's hit points need the (u, v) that k_shade files away) or adds to the colours (god ray)
+    const bool fused = direct && s->dev.n_lights > 0 && !s->god && !s->keep_uv;
     if (s->dev.n_lights > 0) {
       ProfScope ps(s, RT_HIP_K_SHADOW, st);
       const unsigned int *ord = (lv == 0) ? (const unsigned int *)order1 : nullptr;
@@ -1280,6 +1339,20 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     hipLaunchKernelGGL(k_classify, dim3((unsigned int)((n_waves + 255) / 256)), dim3(256), 0, st, s->dev, A, (unsigned int)n_waves, flags0);
     hipLaunchKernelGGL(k_order_count, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, ocounts);
     hipLaunchKernelGGL(k_order, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, (const unsigned int *)ocounts, order0);
+  }
+  const int cam_depth = A.cam.depth < 1 ? 1 : A.cam.depth;
+  if (direct_rgb && cam_depth == 1 && s->dev.n_lights > 0 && !s->god && !s->keep_uv && !A.focusing && A.n_samples == 1) {
+    rc = s->lum.ensure((size_t)n0 * s->dev.n_lights * sizeof(double)); if (rc) return rc;
+    {
+      ProfScope ps(s, RT_HIP_K_FRAME_DIRECT, st);
+      RT_LAUNCH_SP(k_frame_direct, stats, param, dim3(pblocks), st, s->dev, A, (const unsigned int *)order0, (double *)s->lum.p,
+                   (RenderCounters *)s->counter.p, gs, direct_rgb, direct_id);
+    }
+    HIP_TRY(hipGetLastError());
+    for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) s->last_n_level[lv] = 0;
+    s->last_level = 0;
+    s->last_rays += A.pixel_count;
+    return RT_HIP_OK;
   }
   {
     ProfScope ps(s, RT_HIP_K_PRIMARY, st);
