@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
 // occlusion walk per light sample.  Kept apart from k_shade so that the walk runs at full occupancy.
 template <bool STATS, bool PARAM>
 __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n, double *lum,
-                                                      const unsigned int *order, RenderCounters *cnt, Stats *gstats, double *direct_rgb, int32_t *direct_id)
+                                                      const unsigned int *order, RenderCounters *cnt, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
@@ -699,24 +699,6 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
     const DLight &L = sc.lights[li];
     double l = light_luminosity<STATS, PARAM>(sc, L, li, pt, hit, key, stack, st);
     if (hit) { lum[(size_t)i * sc.n_lights + li] = l; my_shadow += (L.type == 102) ? (unsigned long long)L.sample_num * L.sample_num : 1ull; }
-  }
-  // direct_rgb != NULL (level 0 of a depth-1 frame): the colour is final once the luminosities are known, so the local
-  // illumination (Scene.h:93-122) is evaluated here and goes straight to the frame (Camera.h:69): no shading pass
-  // over the level array.  The node and this lane's luminosities are read back (cache-hot) only now, so that
-  // nothing of the shading is alive during the walks.  Same code as k_shade's.
-  if (direct_rgb && in_range) {
-    const PathNode &nd = nodes[i];
-    if (nd.weight > 0.0) {                            // padding lanes of edge tiles carry weight 0
-      Col c = mkc(A.bg[0], A.bg[1], A.bg[2]);
-      if (hit) {
-        V3 N;
-        const V3 dd = mk(nd.d[0], nd.d[1], nd.d[2]);
-        c = local_illumination<PARAM>(sc, dd, id, pt, lum + (size_t)i * sc.n_lights, N, nd.col[0], nd.col[1]);   // col[0..1] = (u, v)
-      }
-      const uint64_t q = (uint64_t)nd.pixel - A.pixel_first;
-      direct_rgb[3 * q] = c.r; direct_rgb[3 * q + 1] = c.g; direct_rgb[3 * q + 2] = c.b;
-      if (direct_id) direct_id[q] = id;
-    }
   }
   // ray census (always on: it is what rt_hip_last_ray_count reports)
   for (int off = 32; off > 0; off >>= 1) my_shadow += __shfl_down(my_shadow, off, 64);
@@ -1274,16 +1256,12 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
     rc = s->lum.ensure((size_t)n * std::max(1, s->dev.n_lights) * sizeof(double)); if (rc) return rc;
     double *lum = (double *)s->lum.p;
     const bool direct = direct_rgb && lv == 0 && depth == 1;
-    // the shadow pass shades and writes the frame itself -- unless someone reads the level array afterwards
-    // (photon mapping's hit points need the (u, v) that k_shade files away) or adds to the colours (god ray)
-    const bool fused = direct && s->dev.n_lights > 0 && !s->god && !s->keep_uv;
     if (s->dev.n_lights > 0) {
       ProfScope ps(s, RT_HIP_K_SHADOW, st);
       const unsigned int *ord = (lv == 0) ? (const unsigned int *)order1 : nullptr;
-      RT_LAUNCH_SP(k_shadow, stats, param, dim3(blocks_for(n)), st, s->dev, A, (const PathNode *)cur, n, lum, ord, cnt, gs,
-                   fused ? direct_rgb : (double *)nullptr, fused ? direct_id : (int32_t *)nullptr);
+      RT_LAUNCH_SP(k_shadow, stats, param, dim3(blocks_for(n)), st, s->dev, A, (const PathNode *)cur, n, lum, ord, cnt, gs);
     }
-    if (!fused) {
+    {
       ProfScope ps(s, RT_HIP_K_SHADE, st);
       double *uv_out = nullptr;
       if (s->keep_uv && param) { rc = s->uv[lv].ensure((size_t)n * 16); if (rc) return rc; uv_out = (double *)s->uv[lv].p; }

@@ -417,6 +417,19 @@ def test_ppm_wine_scene(ctx):
     _ppm_compare(ctx, g, o, cam_args, photon_num=1500, times=2, what="ppm C5", min_hp=2000)
 
 
+def test_ppm_depth1_camera(ctx):
+    """a depth-1 eye pass keeps its level array (hit points, (u, v) of the surfaces of revolution) although a depth-1
+    frame on its own is rendered in one launch without one"""
+    g, o = scenes.build_wine(light="area", cup_material="porcelain")
+    cam_args = dict(scenes.C5_CAMERA, res=10, depth=1)
+    _ppm_compare(ctx, g, o, cam_args, photon_num=1500, times=1, what="ppm depth 1", min_hp=3000)
+    import ray_tracing_amd as rta
+    cam = rta.Camera(**cam_args)                      # and the plain depth-1 frame of the same scene (k_frame_direct, PARAM)
+    cam.render_raytracer(ctx, g, background=(10, 10, 10))
+    rgb_ref, ids_ref = scenes.oracle_render_whitted(o, cam_args, background=(10, 10, 10))
+    assert (cam.prim_id() != ids_ref).mean() <= 1e-4 and (_rel_err(cam.rgb(), rgb_ref).max(axis=1) >= 1e-3).mean() <= 1e-4
+
+
 def test_ppm_photon_shards_add_up(ctx):
     """multi-GPU hook: a pass traced as three photon ranges gives the accumulators of the pass traced at once"""
     import torch
