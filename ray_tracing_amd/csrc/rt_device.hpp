@@ -1046,14 +1046,14 @@ struct RngKey { uint64_t seed; uint32_t pixel, sample, path; };
 // Light.h:62-69 / 87-94, CAreaLight::luminosity (Light.h:126-162) and luminosity_BSPTree
 // (Scene.h:436-455).  Every shadow query is a wave-packet occlusion walk; point and parallel lights are
 // the one-sample case of the same loop.
-template <bool STATS, bool PARAM, bool PF = false>
+template <bool STATS, bool PARAM, bool PF = false, bool ONE = false>
 __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLight &L, int li, V3 pt, bool active,
                                                    const RngKey &key, WaveLds *lds, Stats &st)
 {
   const V3 lp = mk(L.p[0], L.p[1], L.p[2]);
   const int type = uni(L.type);
   const bool area = (type == 102);
-  const int sn = area ? uni(L.sample_num) : 1;
+  const int sn = ONE ? 1 : (area ? uni(L.sample_num) : 1);      // ONE: the caller has checked that this light has one sample
   const double rr = area ? (L.len / double(sn)) / 2 : 0.0;
   const V3 O = mk(lp.x - sn * rr, lp.y - sn * rr, lp.z);
   const double per = area ? L.lum_per_sample : L.lum;

@@ -84,6 +84,7 @@ struct rt_hip_scene {
   uint64_t last_rays = 0, last_shadow = 0;
   unsigned int last_n_level[kMaxLevels] = {0}; int last_level = 0;   // sizes of the level arrays of the last run
   bool keep_uv = false;            // photon mapping eye pass: keep the (u, v) of every node's hit (k_shade overwrites them)
+  bool one_sample = false;         // exactly one light and it takes one shadow ray per point: k_frame_direct has a loop-free form for it
   DevBuf uv[kMaxLevels];
   DevBuf aa_maps, aa_edges;        // anti-aliasing drivers: G-buffer maps, list of masked pixels
   uint64_t last_aa_edges = 0;
@@ -587,7 +588,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
 // A depth-1 frame in ONE launch (Camera.h:53-75 with depth == 1): camera ray + closest hit as in k_primary, the
 // luminosities as in k_shadow, the local illumination, the frame.  Nothing goes through a level array, and the
 // low-occupancy tail of the primary pass disappears into the shadow walks of the same waves.
-template <bool STATS, bool PARAM>
+template <bool STATS, bool PARAM, bool ONE = false>
 __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_frame_direct(DevScene sc, RenderArgs A, const unsigned int *order, double *lum,
                                                                           RenderCounters *cnt, Stats *gstats, double *rgb, int32_t *prim_id)
 {
@@ -605,6 +606,8 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   Stats st{};
   // Camera.h:65-67; evaluated again after the walks instead of being kept alive across them
   auto camera_ray = [&](V3 &o, V3 &d) {
+    unsigned int s2, tx2, ty2; tile_of_wave(A, wave, s2, tx2, ty2);
+    const unsigned int h = tx2 * 8 + (lane & 7), v = A.v_lo + ty2 * 8 + (lane >> 3);
     V3 cur = A.cam.start - A.cam.left * (double(h) / double(A.cam.res)) - A.cam.up * (double(v) / double(A.cam.res));
     o = A.cam.view_pt;
     d = unitize(unitize(cur - o));
@@ -621,22 +624,29 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   }
   const bool hit = active && id >= 0;
   if (!hit) pt = mk(0, 0, 0);
-  const size_t i = (size_t)wave * 64 + lane;
-  RngKey key; key.seed = A.seed; key.pixel = (uint32_t)p; key.sample = A.sample_first + s_local; key.path = 1;
-  unsigned long long my_shadow = 0;
-  for (int li = 0; li < sc.n_lights; li++) {
+  // what lives across the light walks is pt, id and the pixel number; the rest is made again where it is used
+  const uint32_t pix = (uint32_t)p;
+  const int nl = ONE ? 1 : sc.n_lights;      // ONE: one light of one sample, so neither loop exists and nothing is hoisted across the walk
+  for (int li = 0; li < nl; li++) {
     const DLight &L = sc.lights[li];
-    double l = light_luminosity<STATS, PARAM, true>(sc, L, li, pt, hit, key, stack, st);
-    if (hit) { lum[i * sc.n_lights + li] = l; my_shadow += (L.type == 102) ? (unsigned long long)L.sample_num * L.sample_num : 1ull; }
+    RngKey key; key.seed = A.seed; key.pixel = pix; key.sample = A.sample_first + s_local; key.path = 1;
+    double l = light_luminosity<STATS, PARAM, true, ONE>(sc, L, li, pt, hit, key, stack, st);
+    if (hit) lum[((size_t)wave * 64 + lane) * nl + li] = l;
   }
   if (active) {
     Col c = mkc(A.bg[0], A.bg[1], A.bg[2]);
-    if (hit) { V3 o, d, N; camera_ray(o, d); c = local_illumination<PARAM>(sc, d, id, pt, lum + i * sc.n_lights, N, hu, hv); }
-    const uint64_t q = p - A.pixel_first;
+    if (hit) { V3 o, d, N; camera_ray(o, d); c = local_illumination<PARAM>(sc, d, id, pt, lum + ((size_t)wave * 64 + lane) * nl, N, hu, hv); }
+    const uint64_t q = (uint64_t)pix - A.pixel_first;
     rgb[3 * q] = c.r; rgb[3 * q + 1] = c.g; rgb[3 * q + 2] = c.b;
     if (prim_id) prim_id[q] = id;
   }
-  for (int off = 32; off > 0; off >>= 1) my_shadow += __shfl_down(my_shadow, off, 64);
+  // shadow rays of this wave: the count per shaded point does not depend on the walks
+  unsigned long long per_hit = 0;
+  for (int li = 0; li < sc.n_lights; li++) {
+    const DLight &L = sc.lights[li];
+    per_hit += (L.type == 102) ? (unsigned long long)L.sample_num * L.sample_num : 1ull;
+  }
+  const unsigned long long my_shadow = per_hit * (unsigned long long)__popcll(__ballot(hit));
   if (lane == 0 && my_shadow) atomicAdd(&cnt->shadow_rays, my_shadow);
   if (STATS) stats_flush(gstats, st);
 }
@@ -1025,6 +1035,7 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
     o.type = L.type; o.sample_num = L.sample_num; std::memcpy(o.p, L.pos_or_dir, 24); o.lum = L.luminosity; o.len = L.len;
     o.lum_per_sample = (L.type == RT_HIP_AREA_LIGHT) ? L.luminosity / (L.sample_num * L.sample_num) : 0.0;   // Light.h:107
   }
+  s->one_sample = d->n_lights == 1 && (d->lights[0].type != RT_HIP_AREA_LIGHT || d->lights[0].sample_num == 1);
   std::vector<uint8_t> types(d->obj_type, d->obj_type + d->n_objects);
   std::vector<uint32_t> index(d->obj_index, d->obj_index + d->n_objects), omat(d->obj_material, d->obj_material + d->n_objects);
   std::vector<double> colour(d->obj_colour, d->obj_colour + 3 * (size_t)d->n_objects);
@@ -1324,8 +1335,12 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     rc = s->lum.ensure((size_t)n0 * s->dev.n_lights * sizeof(double)); if (rc) return rc;
     {
       ProfScope ps(s, RT_HIP_K_FRAME_DIRECT, st);
-      RT_LAUNCH_SP(k_frame_direct, stats, param, dim3(pblocks), st, s->dev, A, (const unsigned int *)order0, (double *)s->lum.p,
-                   (RenderCounters *)s->counter.p, gs, direct_rgb, direct_id);
+      if (!stats && !param && s->one_sample)
+        hipLaunchKernelGGL((k_frame_direct<false, false, true>), dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, (const unsigned int *)order0,
+                           (double *)s->lum.p, (RenderCounters *)s->counter.p, gs, direct_rgb, direct_id);
+      else
+        RT_LAUNCH_SP(k_frame_direct, stats, param, dim3(pblocks), st, s->dev, A, (const unsigned int *)order0, (double *)s->lum.p,
+                     (RenderCounters *)s->counter.p, gs, direct_rgb, direct_id);
     }
     HIP_TRY(hipGetLastError());
     for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) s->last_n_level[lv] = 0;
