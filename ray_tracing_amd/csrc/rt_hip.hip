@@ -1087,6 +1087,7 @@ extern "C" int rt_hip_scene_share(rt_hip_scene *src, rt_hip_scene **out)
   rt_hip_scene *s = new rt_hip_scene();
   s->ctx = src->ctx; s->dev = src->dev; s->geo = src->geo;
   s->n_nodes = src->n_nodes; s->n_leaves = src->n_leaves; s->n_cull = src->n_cull; s->max_depth = src->max_depth;
+  s->one_sample = src->one_sample;
   *out = s;
   return RT_HIP_OK;
 }
