@@ -73,7 +73,11 @@ def _rel_err(a, b):
 
 @pytest.mark.parametrize("material,light,depth", [("plastic", "point_area", 1), ("metal", "point_area", 3),
                                                   ("glass", "two", 4), ("metal", "area3", 2), ("porcelain", "point", 2),
-                                                  ("mirror", "parallel", 3)])
+                                                  ("mirror", "parallel", 3),
+                                                  # depth 1 = the one-launch frame kernel: its loop-free form (one light of
+                                                  # one shadow ray: point_area above, point, parallel) and its general form
+                                                  ("rubber", "point", 1), ("plastic", "parallel", 1), ("plastic", "two", 1),
+                                                  ("plastic", "area3", 1)])
 def test_whitted_image_parity(ctx, material, light, depth):
     import ray_tracing_amd as rta
     g, o = scenes.build_icosahedron(material=material, light=light, extra_sphere=True)
