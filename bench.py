@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=int, default=708, help="heightfield cells per side (708 -> 1,002,528 triangles)")
-    ap.add_argument("--leaf-refine", type=int, default=None, help="library leaf refinement (default: library default, 32)")
+    ap.add_argument("--leaf-refine", type=int, default=None, help="rt_hip_scene_create leaf_refine (include/rt_hip.h; default: the library's own hierarchy)")
     ap.add_argument("--mode", choices=["frames", "samples"], default="frames")
     ap.add_argument("--streams", type=int, default=2, help="frames in flight per GPU (one scene handle and HIP stream each)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
@@ -278,7 +278,7 @@ def main():
            "config": {"workload": "C2: synthetic %d-triangle heightfield + ground plane, primary+shadow ray casting %dx%d, 1 frame per GPU per step"
                                   % (n_tris, W, H), "triangles": n_tris, "resolution": [W, H], "rays_per_frame": int(rays_per_frame),
                       "shadow_rays_per_frame": int(shadow_pf.value), "parallelism": "%s x%d" % (args.mode, world), "frames_in_flight": S, "ms_per_frame_one_in_flight": round(ms_one_in_flight, 4),
-                      "leaf_refine": "library default (32)" if args.leaf_refine is None else args.leaf_refine, "scene_build_s": round(build_s, 2), "event_ms_per_step": round(ev_ms / args.steps, 4)},
+                      "leaf_refine": "library default (own hierarchy, leaves < 24)" if args.leaf_refine is None else args.leaf_refine, "scene_build_s": round(build_s, 2), "event_ms_per_step": round(ev_ms / args.steps, 4)},
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -172,13 +172,20 @@ int rt_hip_get_stats(rt_hip_ctx *ctx, rt_hip_stats *out, int reset);
 
 /* ---- scene: replaces CScene::ConstructBSPTree's product (Scene.h:286-293) ----------- */
 /* Copies the description to the device (replicated per GPU) and derives the traversal layout.
- * leaf_refine lets the library split the reference's leaves (< 100 objects, BSPTree.h:56-60) further
- * with the same spatial-median rule (BSPTree.h:58-109) down to fewer than that many objects -- an
- * acceleration detail that cannot change any result (every hit is confirmed with the reference's own
- * arithmetic).  RT_HIP_LEAF_REFINE_DEFAULT picks the library's tuned value (32),
- * RT_HIP_LEAF_REFINE_NONE keeps the reference's leaves as they are. */
+ * The description carries the reference's tree (nodes, leaf references, root objects); which tree the device
+ * walks is the library's business, because the closest hit does not depend on it: an object is listed in every
+ * cell that its box overlaps (the reference's own rule, Object.h:212-222), candidates of a leaf are compared as
+ * in Scene.h:349-387, and every hit is confirmed with the reference's arithmetic.  leaf_refine selects:
+ *   RT_HIP_LEAF_REFINE_DEFAULT      the library's own hierarchy over the finite objects: an object partition
+ *                                   (every object in one leaf, child boxes = bounds of their objects, cuts chosen
+ *                                   by a surface-area cost), tuned leaf size;
+ *   RT_HIP_LEAF_REFINE_NONE         the reference's tree exactly as described (leaves < 100 objects, BSPTree.h:56-60);
+ *   n (2 ...)                       the reference's tree, its leaves split further down to fewer than n objects;
+ *   RT_HIP_LEAF_REFINE_OWN | n      the library's own hierarchy with leaves of fewer than n objects.
+ * A description without nodes (ConstructBSPTree never called) has no tree in any mode (Scene.h:87-88). */
 #define RT_HIP_LEAF_REFINE_DEFAULT 0u
 #define RT_HIP_LEAF_REFINE_NONE    0xFFFFFFFFu
+#define RT_HIP_LEAF_REFINE_OWN     0x40000000u
 int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *desc, uint32_t leaf_refine, rt_hip_scene **out);
 int rt_hip_scene_destroy(rt_hip_scene *scene);
 /* Another handle on the same scene: shares the geometry in HBM (released with the last handle), owns its
