@@ -754,19 +754,25 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   if (!hit) pt = mk(0, 0, 0);
   // what lives across the light walks is pt, id and the pixel number; the rest is made again where it is used
   const uint32_t pix = (uint32_t)p;
+  double l_one = 0;                           // ONE: the one luminosity stays in a register
   const int nl = ONE ? 1 : sc.n_lights;      // ONE: one light of one sample, so neither loop exists and nothing is hoisted across the walk
   for (int li = 0; li < nl; li++) {
     const DLight &L = sc.lights[li];
     RngKey key; key.seed = A.seed; key.pixel = pix; key.sample = A.sample_first + s_local; key.path = 1;
     double l = light_luminosity<STATS, PARAM, true, ONE>(sc, L, li, pt, hit, key, stack, st);
-    if (hit) lum[((size_t)wave * 64 + lane) * nl + li] = l;
+    if (ONE) l_one = l;
+    else if (hit) lum[((size_t)wave * 64 + lane) * nl + li] = l;
   }
   if (active) {
     Col c = mkc(A.bg[0], A.bg[1], A.bg[2]);
-    if (hit) { V3 o, d, N; camera_ray(o, d); c = local_illumination<PARAM>(sc, d, id, pt, lum + ((size_t)wave * 64 + lane) * nl, N, hu, hv); }
+    if (hit) {
+      V3 o, d, N; camera_ray(o, d);
+      c = local_illumination<PARAM>(sc, d, id, pt, ONE ? &l_one : lum + ((size_t)wave * 64 + lane) * nl, N, hu, hv);
+    }
+    // the frame is written once and read by nobody on this GPU: streamed past the L2 lines that hold the hierarchy
     const uint64_t q = (uint64_t)pix - A.pixel_first;
-    rgb[3 * q] = c.r; rgb[3 * q + 1] = c.g; rgb[3 * q + 2] = c.b;
-    if (prim_id) prim_id[q] = id;
+    __builtin_nontemporal_store(c.r, &rgb[3 * q]); __builtin_nontemporal_store(c.g, &rgb[3 * q + 1]); __builtin_nontemporal_store(c.b, &rgb[3 * q + 2]);
+    if (prim_id) __builtin_nontemporal_store(id, &prim_id[q]);
   }
   // shadow rays of this wave: the count per shaded point does not depend on the walks
   unsigned long long per_hit = 0;
