@@ -67,6 +67,40 @@ def test_random_rays_mixed_scene(ctx, refine):
     _compare_hits(rays2, hits2, ids2, pts2, "secondary refine=%d" % refine)
 
 
+@pytest.mark.parametrize("refine", [0, 0x40000000 | 3, 4])
+def test_degenerate_content_hierarchy(ctx, refine):
+    """Content no plane can separate: 30 coincident triangles and 60 coplanar concentric ones with one common box centre
+    (the own hierarchy falls back to halving the list; hits at equal distance go to the first-listed object, Scene.h:74-79),
+    plus a fan around one vertex.  Fewer than 100 objects, so the reference's root stays a leaf (BSPTree.h:60)."""
+    P = scenes._Pair(0.5, True, True)
+    plastic = P.mat("plastic")
+    base = np.array([(0.0, 0.0, 1.0), (2.0, 0.2, 1.0), (0.7, 1.9, 1.0)])
+    for _ in range(30):
+        P.call("add_triangle", [tuple(v) for v in base + np.array([3.0, 0, 0])], None, mat=plastic, colour=(200, 10, 10))
+    c = (base.min(axis=0) + base.max(axis=0)) / 2
+    for k in range(60):
+        P.call("add_triangle", [tuple(v) for v in c + (0.2 + 0.03 * k) * (base - c)], None, mat=plastic, colour=(10, 200, 10))
+    for k in range(8):
+        a0, a1 = 0.7 * k, 0.7 * (k + 1)
+        P.call("add_triangle", [(-2.0, 0.0, 0.5), (-2 + np.cos(a0), np.sin(a0), 0.5 + 0.1 * k), (-2 + np.cos(a1), np.sin(a1), 0.6 + 0.1 * k)],
+               None, mat=plastic, colour=(10, 10, 200))
+    P.call("construct_bsp")
+    P.call("add_area_light", (-10, 20, 20), 1.0, 0.0, 1)
+    P.g.set_leaf_refine(refine)
+    g, o = P.g, P.o
+    rng = np.random.default_rng(12)
+    n = 30000
+    org = rng.uniform(-4, 6, (n, 3)) * np.array([1, 0.6, 0]) + np.array([0, 0, 4.0])
+    tgt = rng.uniform(0, 1, (n, 3)) * np.array([7.0, 2.5, 0.5]) + np.array([-3.0, -0.5, 0.6])
+    rays = np.concatenate([org, tgt - org], axis=1)
+    ids_ref, pts_ref = o.trace_closest(rays, use_bsp=True)
+    hits = g.first_inter_pt(ctx, rays, use_tree=True)
+    assert (ids_ref >= 0).mean() > 0.2
+    assert (hits["prim_id"] == ids_ref).all()          # equal-distance hits included: the first-listed object wins on both sides
+    hit = ids_ref >= 0
+    assert np.abs(hits["t"][hit] - np.linalg.norm(pts_ref[hit] - rays[hit, :3], axis=1)).max() < 1e-9
+
+
 def _rel_err(a, b):
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
