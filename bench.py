@@ -129,7 +129,10 @@ def main():
             # radiance all-reduce of this step overlaps the next step's render
             comm_stream.wait_stream(fl_streams[step % S])
             with torch.cuda.stream(comm_stream):
-                dist.all_reduce(buf)
+                if rehearsal:                      # gloo: the collective runs on a host copy (N ranks rehearsed on one GPU)
+                    host = buf.cpu(); dist.all_reduce(host); buf.copy_(host)
+                else:
+                    dist.all_reduce(buf)
         return cam
 
     def barrier():
