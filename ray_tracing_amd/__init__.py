@@ -78,6 +78,7 @@ class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 12), ("launches", C.c_uint64 * 12)]
 
 
+LEAF_REFINE_DEFAULT, LEAF_REFINE_NONE, LEAF_REFINE_OWN = 0, 0xFFFFFFFF, 0x40000000      # include/rt_hip.h
 KERNEL_NAMES = ["k_primary", "k_trace_nodes", "k_shade", "k_combine", "k_resolve", "k_trace_closest", "k_trace_occluded", "k_shadow", "k_order", "k_aa", "k_frame_direct", "-"]
 
 hip.rt_hip_last_error.restype = C.c_char_p
@@ -465,6 +466,8 @@ class Scene:
         _chk_host(host.rth_construct_bsp(self._h, max_obj_num, max_depth))
 
     def set_leaf_refine(self, n):
+        """which hierarchy the device walks (include/rt_hip.h): LEAF_REFINE_DEFAULT = the library's own, LEAF_REFINE_NONE =
+        the reference's tree as built, n = that tree with leaves split down to n objects, LEAF_REFINE_OWN | n = own, leaf size n"""
         host.rth_set_leaf_refine(self._h, n)
 
     @property

@@ -44,7 +44,7 @@ def test_c1_hit_ids_bsp_and_brute(ctx):
     _compare_hits(rays[sub], hb, ids_ref[sub], pts_ref[sub], "C1 brute")
 
 
-@pytest.mark.parametrize("refine", [0xFFFFFFFF, 0, 8, 0x40000000 | 3])   # rt_hip.h: reference tree, own hierarchy, refined reference tree, own with tiny leaves
+@pytest.mark.parametrize("refine", [0xFFFFFFFF, 0, 8, 0x40000000 | 3])   # rt_hip.h (LEAF_REFINE_*): reference tree, own hierarchy, refined reference tree, own with tiny leaves
 def test_random_rays_mixed_scene(ctx, refine):
     g, o = scenes.build_icosahedron(extra_sphere=True, leaf_refine=refine)
     rng = np.random.default_rng(7)
