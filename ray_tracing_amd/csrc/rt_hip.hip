@@ -103,7 +103,7 @@ struct RenderCounters { unsigned int queue_count; unsigned int pad; unsigned lon
 // scene preparation (host)
 // ================================================================================================
 namespace {
-constexpr uint32_t kOwnLeaf = 24;   // leaf size of the library's own hierarchy (C2 sweep: 16..24 within 1 %)
+constexpr uint32_t kOwnLeaf = 24;   // leaf size of the library's own hierarchy (C2 sweep: 16..28 within 1 %; 16, 32 or 64 cuts per axis make no difference either)
 
 struct Box { double mn[3], mx[3]; };
 
