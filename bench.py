@@ -37,8 +37,8 @@ FP64_VALU_PEAK_TF = 78.6   # MI355X vector FP64 (spec, FMA = 2 flop)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cells", type=int, default=708, help="heightfield cells per side (708 -> 1,002,528 triangles)")
     ap.add_argument("--leaf-refine", type=int, default=None, help="rt_hip_scene_create leaf_refine (include/rt_hip.h; default: the library's own hierarchy)")
     ap.add_argument("--mode", choices=["frames", "samples"], default="frames")
