@@ -77,7 +77,7 @@ struct DevScene {
   const DPair *pairs; const unsigned char *leaf_stream;
   ChildRef root; int32_t has_tree;              // has_tree == 0: CScene::FirstInterPt over all objects
   const int32_t *root_objs; int32_t n_root_objs;// bspTree.root->objects (infinite objects)
-  const TriExact *tri_exact; const TriShade *tri_shade;
+  const TriExact *tri_exact; const TriShade *tri_shade;   // tri_shade == NULL: no triangle has vertex normals
   const DPlane *planes; const DSphere *spheres; const DCircle *circles;
   const DBezier *beziers; const DRotational *rotationals;
   int32_t has_param;                            // the scene holds Bezier / rotational objects: kernels built with PARAM
@@ -844,6 +844,7 @@ __device__ __forceinline__ V3 object_initial_norm(const DevScene &sc, int id, V3
   }
   if (type == 1) {                                    // CTriangle::InitialNorm, Object.h:448-457
     const TriExact &T = sc.tri_exact[k];
+    if (!sc.tri_shade) return mk(T.nrm[0], T.nrm[1], T.nrm[2]);      // no triangle of the scene has vertex normals
     const TriShade &S = sc.tri_shade[k];
     if (!S.has_vn) return mk(T.nrm[0], T.nrm[1], T.nrm[2]);
     V3 v0 = mk(T.v0[0], T.v0[1], T.v0[2]), v1 = mk(T.v1[0], T.v1[1], T.v1[2]), v2 = mk(T.v2[0], T.v2[1], T.v2[2]);

@@ -1200,7 +1200,15 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
     }
   }
   up(upload(s, B.pairs, &D.pairs)); up(upload(s, B.stream, &D.leaf_stream));
-  up(upload(s, root_objs, &D.root_objs)); up(upload(s, B.tri_exact, &D.tri_exact)); up(upload(s, tri_shade, &D.tri_shade));
+  up(upload(s, root_objs, &D.root_objs)); up(upload(s, B.tri_exact, &D.tri_exact));
+  {
+    // vertex normals only where a mesh has them (Object.h:448-457): a flat-shaded scene keeps 80 bytes per triangle out of HBM
+    // and one scattered line per shaded point out of the caches
+    bool any_vn = false;
+    for (const TriShade &S : tri_shade) if (S.has_vn) { any_vn = true; break; }
+    D.tri_shade = nullptr;
+    if (any_vn) up(upload(s, tri_shade, &D.tri_shade));
+  }
   up(upload(s, planes, &D.planes)); up(upload(s, spheres, &D.spheres)); up(upload(s, circles, &D.circles));
   up(upload(s, beziers, &D.beziers)); up(upload(s, rots, &D.rotationals));
   D.has_param = (d->n_beziers || d->n_rotationals) ? 1 : 0;
