@@ -221,6 +221,21 @@ int rt_hip_render_whitted(rt_hip_scene *scene, const rt_hip_camera *cam, const r
 int rt_hip_render_whitted_dev(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
                               double *d_rgb, int32_t *d_prim_id, void *stream);
 
+/* NO counterpart in the reference.  rt_hip_render_whitted_dev for callers that cannot allocate device memory: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and same results as
+ * rt_hip_render_whitted_dev for a camera of depth 1 (Camera.h:53-75 with depth == 1: closest hit, luminosities, local
+ * illumination; the frame of BASELINE config C2); the workspace (ray counters, heavy-first wave order, per-light
+ * luminosities) lives in a fixed 32 MiB array that every GPU the library runs on holds until the process ends, so the
+ * call makes no hipMalloc / hipFree and creates no events or streams.  Limits: camera depth 1, a scene with at least
+ * one light, and 256 + 10.1 bytes per 8x8-pixel tile + (unless the scene has exactly one light of one shadow ray)
+ * 8 bytes per padded pixel and light must fit the array -- a 1920x1080 frame with up to one multi-sample light, or
+ * any frame up to ~25 Mpixel with one single-sample light; RT_HIP_EINVAL with the byte counts otherwise.  All calls
+ * on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads, two scene handles)
+ * race; calls on one stream are ordered and safe.  rt_hip_last_ray_count reports this call's rays until the next
+ * allocation-free call on the same GPU overwrites the counters. */
+int rt_hip_render_whitted_noalloc(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
+                                  double *d_rgb, int32_t *d_prim_id, void *stream);
+
 /* CCamera::Render_Focusing (Camera.h:171-199): spp lens samples per pixel.  The output is the SUM over
  * the sample shard of sample_colour/spp WITHOUT the running clamp, so that shards add up
  * (all-reduce) and one final min(255, .) gives the reference's clamped running sum (every term

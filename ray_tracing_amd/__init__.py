@@ -151,6 +151,7 @@ hip.rt_hip_trace_occluded.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]
 hip.rt_hip_camera_size.argtypes = [C.POINTER(CameraStruct), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
 hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
+hip.rt_hip_render_whitted_noalloc.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_render_focusing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp]
 hip.rt_hip_render_focusing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
 hip.rt_hip_render_antialiasing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.POINTER(AaParams), _vp, _vp]

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 using namespace rt;
@@ -82,6 +83,7 @@ struct rt_hip_scene {
   DevBuf counter;                 // queue counter + per-render ray counters
   DevBuf staging;                 // host-pointer entry points
   uint64_t last_rays = 0, last_shadow = 0;
+  const void *last_counters = nullptr;   // RenderCounters of the last render call (the scene's own, or the allocation-free entry point's)
   unsigned int last_n_level[kMaxLevels] = {0}; int last_level = 0;   // sizes of the level arrays of the last run
   bool keep_uv = false;            // photon mapping eye pass: keep the (u, v) of every node's hit (k_shade overwrites them)
   bool one_sample = false;         // exactly one light and it takes one shadow ray per point: k_frame_direct has a loop-free form for it
@@ -979,6 +981,30 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(const PathNode *nodes, Ren
 }
 
 // ================================================================================================
+// workspace of the allocation-free entry point (rt_hip_render_whitted_noalloc, below)
+// ================================================================================================
+// One fixed array per GPU, resident from the moment the library's code object is loaded on that GPU until the process
+// ends.  In host code the NAME of the array is only a stand-in (it is not a device address): the address on each device
+// is asked for once, with that device current, in rt_hip_context_create, and kept per device in g_scratch_ptr.
+#define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
+#define RT_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+static unsigned char *g_scratch_ptr[RT_MAX_DEVICES] = {nullptr};
+static std::mutex g_scratch_mutex;
+// called with `device` current
+static int scratch_setup(int device)
+{
+  if (device < 0 || device >= RT_MAX_DEVICES) return RT_HIP_OK;      // such a device has no allocation-free entry point (it says so when called)
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device]) return RT_HIP_OK;
+  void *ptr = nullptr;
+  HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+  if (!ptr) return fail(RT_HIP_EHIP, "hipGetSymbolAddress(scratch) returned NULL");
+  g_scratch_ptr[device] = (unsigned char *)ptr;
+  return RT_HIP_OK;
+}
+
+// ================================================================================================
 // C ABI
 // ================================================================================================
 extern "C" int rt_hip_device_count(int *n)
@@ -1000,6 +1026,7 @@ extern "C" int rt_hip_context_create(int device_id, rt_hip_ctx **out)
   if (c <= 0) return fail(RT_HIP_EHIP, "no HIP device: this library has no CPU fallback");
   if (device_id < 0 || device_id >= c) return fail(RT_HIP_EINVAL, "device_id out of range");
   HIP_TRY(hipSetDevice(device_id));
+  { int rc = scratch_setup(device_id); if (rc) return rc; }
   rt_hip_ctx *ctx = new rt_hip_ctx();
   ctx->device = device_id;
   hipError_t e = hipMalloc((void **)&ctx->d_stats, sizeof(Stats));
@@ -1255,7 +1282,7 @@ struct ProfScope {
   rt_hip_scene *s; hipStream_t st; rt_hip_scene::EvPair *e = nullptr;
   ProfScope(rt_hip_scene *s_, int k, hipStream_t st_) : s(s_), st(st_)
   {
-    if (!s->prof_on) return;
+    if (!s || !s->prof_on) return;
     if (s->ev_used == s->ev_pool.size()) {
       if (s->ev_pool.size() >= 8192) { if (prof_flush(s) != RT_HIP_OK) return; }
       else {
@@ -1452,58 +1479,79 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
 }
 
 
-// the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
-static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, double *direct_rgb = nullptr, int32_t *direct_id = nullptr)
+// bytes of the heavy-first order workspace for n_waves level-0 waves: two order lists, the per-block counts, two flag arrays
+static inline size_t order_bytes(uint64_t n_waves) { return (size_t)n_waves * 10 + (size_t)((n_waves + 1023) / 1024) * 4 + 64; }
+struct OrderBufs { unsigned int *order0 = nullptr, *order1 = nullptr, *ocounts = nullptr; unsigned char *flags0 = nullptr, *flags1 = nullptr; unsigned int oblocks = 0; };
+// classification of the level-0 waves + their heavy-first order (k_classify, k_order_count, k_order) in `mem` (order_bytes(n_waves))
+static int order_waves(rt_hip_scene *s, const RenderArgs &A, uint64_t n_waves, void *mem, hipStream_t st, OrderBufs &O, bool prof)
 {
-  const uint64_t n_waves = (uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * A.n_samples;
-  const uint64_t n0 = n_waves * 64;      // level 0 in tile order, edge tiles padded
-  if (A.pixel_count == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
-  int rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
-  rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
+  O.oblocks = (unsigned int)((n_waves + 1023) / 1024);
+  O.order0 = (unsigned int *)mem; O.order1 = O.order0 + n_waves; O.ocounts = O.order1 + n_waves;
+  O.flags0 = (unsigned char *)(O.ocounts + O.oblocks); O.flags1 = O.flags0 + n_waves;
+  rt_hip_scene *ps = prof ? s : nullptr;
+  ProfScope scope(ps, RT_HIP_K_ORDER, st);
+  hipLaunchKernelGGL(k_classify, dim3((unsigned int)((n_waves + 255) / 256)), dim3(256), 0, st, s->dev, A, (unsigned int)n_waves, O.flags0);
+  hipLaunchKernelGGL(k_order_count, dim3(O.oblocks), dim3(1024), 0, st, (const unsigned char *)O.flags0, (unsigned int)n_waves, O.ocounts);
+  hipLaunchKernelGGL(k_order, dim3(O.oblocks), dim3(1024), 0, st, (const unsigned char *)O.flags0, (unsigned int)n_waves, (const unsigned int *)O.ocounts, O.order0);
+  HIP_TRY(hipGetLastError());
+  return RT_HIP_OK;
+}
+// a depth-1 frame in one launch (k_frame_direct); lum: n0 * n_lights doubles, not read when the scene has one light of one sample
+static int launch_frame_direct(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, uint64_t n_waves, const unsigned int *order0,
+                               double *lum, RenderCounters *cnt, double *rgb, int32_t *ids, bool prof)
+{
   Stats *gs = stats ? s->ctx->d_stats : nullptr;
   const bool param = s->dev.has_param != 0;
   const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
-  PathNode *L0 = (PathNode *)s->levels[0].p;
+  {
+    ProfScope ps(prof ? s : nullptr, RT_HIP_K_FRAME_DIRECT, st);
+    if (!stats && !param && s->one_sample)
+      hipLaunchKernelGGL((k_frame_direct<false, false, true>), dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, order0, lum, cnt, gs, rgb, ids);
+    else
+      RT_LAUNCH_SP(k_frame_direct, stats, param, dim3(pblocks), st, s->dev, A, order0, lum, cnt, gs, rgb, ids);
+  }
+  HIP_TRY(hipGetLastError());
+  for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) s->last_n_level[lv] = 0;
+  s->last_level = 0;
+  s->last_rays += A.pixel_count;
+  return RT_HIP_OK;
+}
+static inline uint64_t level0_waves(const RenderArgs &A) { return (uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * A.n_samples; }
+
+// the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
+static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, double *direct_rgb = nullptr, int32_t *direct_id = nullptr)
+{
+  const uint64_t n_waves = level0_waves(A);
+  const uint64_t n0 = n_waves * 64;      // level 0 in tile order, edge tiles padded
+  if (A.pixel_count == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
+  int rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
+  Stats *gs = stats ? s->ctx->d_stats : nullptr;
+  const bool param = s->dev.has_param != 0;
+  const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
   // heavy-first order of the level-0 waves (only worth it with a tree)
-  unsigned int *order0 = nullptr, *order1 = nullptr, *ocounts = nullptr; unsigned char *flags0 = nullptr, *flags1 = nullptr;
-  unsigned int oblocks = 0;
+  OrderBufs O;
   if (s->dev.has_tree) {
-    oblocks = (unsigned int)((n_waves + 1023) / 1024);
-    rc = s->order.ensure(n_waves * 10 + (size_t)oblocks * 4 + 64); if (rc) return rc;
-    order0 = (unsigned int *)s->order.p; order1 = order0 + n_waves; ocounts = order1 + n_waves;
-    flags0 = (unsigned char *)(ocounts + oblocks); flags1 = flags0 + n_waves;
-    ProfScope ps(s, RT_HIP_K_ORDER, st);
-    hipLaunchKernelGGL(k_classify, dim3((unsigned int)((n_waves + 255) / 256)), dim3(256), 0, st, s->dev, A, (unsigned int)n_waves, flags0);
-    hipLaunchKernelGGL(k_order_count, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, ocounts);
-    hipLaunchKernelGGL(k_order, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags0, (unsigned int)n_waves, (const unsigned int *)ocounts, order0);
+    rc = s->order.ensure(order_bytes(n_waves)); if (rc) return rc;
+    rc = order_waves(s, A, n_waves, s->order.p, st, O, true); if (rc) return rc;
   }
   const int cam_depth = A.cam.depth < 1 ? 1 : A.cam.depth;
   if (direct_rgb && cam_depth == 1 && s->dev.n_lights > 0 && !s->god && !s->keep_uv && !A.focusing && A.n_samples == 1) {
-    rc = s->lum.ensure((size_t)n0 * s->dev.n_lights * sizeof(double)); if (rc) return rc;
-    {
-      ProfScope ps(s, RT_HIP_K_FRAME_DIRECT, st);
-      if (!stats && !param && s->one_sample)
-        hipLaunchKernelGGL((k_frame_direct<false, false, true>), dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, (const unsigned int *)order0,
-                           (double *)s->lum.p, (RenderCounters *)s->counter.p, gs, direct_rgb, direct_id);
-      else
-        RT_LAUNCH_SP(k_frame_direct, stats, param, dim3(pblocks), st, s->dev, A, (const unsigned int *)order0, (double *)s->lum.p,
-                     (RenderCounters *)s->counter.p, gs, direct_rgb, direct_id);
-    }
-    HIP_TRY(hipGetLastError());
-    for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) s->last_n_level[lv] = 0;
-    s->last_level = 0;
-    s->last_rays += A.pixel_count;
-    return RT_HIP_OK;
+    if (!s->one_sample) { rc = s->lum.ensure((size_t)n0 * s->dev.n_lights * sizeof(double)); if (rc) return rc; }
+    return launch_frame_direct(s, A, stats, st, n_waves, O.order0, (double *)s->lum.p, (RenderCounters *)s->counter.p, direct_rgb, direct_id, true);
   }
+  rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
+  PathNode *L0 = (PathNode *)s->levels[0].p;
   {
     ProfScope ps(s, RT_HIP_K_PRIMARY, st);
-    RT_LAUNCH_SP(k_primary, stats, param, dim3(pblocks), st, s->dev, A, L0, (const unsigned int *)order0, flags1, gs);
+    RT_LAUNCH_SP(k_primary, stats, param, dim3(pblocks), st, s->dev, A, L0, (const unsigned int *)O.order0, O.flags1, gs);
   }
+  unsigned int *order1 = nullptr;
   if (s->dev.has_tree && s->dev.n_lights > 0) {
     ProfScope ps(s, RT_HIP_K_ORDER, st);
-    hipLaunchKernelGGL(k_order_count, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags1, (unsigned int)n_waves, ocounts);
-    hipLaunchKernelGGL(k_order, dim3(oblocks), dim3(1024), 0, st, (const unsigned char *)flags1, (unsigned int)n_waves, (const unsigned int *)ocounts, order1);
-  } else order1 = nullptr;
+    hipLaunchKernelGGL(k_order_count, dim3(O.oblocks), dim3(1024), 0, st, (const unsigned char *)O.flags1, (unsigned int)n_waves, O.ocounts);
+    hipLaunchKernelGGL(k_order, dim3(O.oblocks), dim3(1024), 0, st, (const unsigned char *)O.flags1, (unsigned int)n_waves, (const unsigned int *)O.ocounts, O.order1);
+    order1 = O.order1;
+  }
   HIP_TRY(hipGetLastError());
   return run_levels_from(s, A, stats, st, n0, order1, A.pixel_count * A.n_samples, direct_rgb, direct_id);
 }
@@ -1536,7 +1584,7 @@ extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *c
   hipStream_t st = (hipStream_t)stream;
   rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
-  s->last_rays = 0; s->last_shadow = 0;
+  s->last_rays = 0; s->last_shadow = 0; s->last_counters = s->counter.p;
   const bool direct = A.cam.depth <= 1;     // a depth-1 frame is final after level 0: k_shade writes it
   rc = run_levels(s, A, P->collect_stats != 0, st, direct ? d_rgb : nullptr, direct ? d_prim_id : nullptr); if (rc) return rc;
   if (!direct) {
@@ -1545,6 +1593,40 @@ extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *c
   }
   HIP_TRY(hipGetLastError());
   return RT_HIP_OK;
+}
+
+// rt_hip_render_whitted_dev for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc): the depth-1 frame in one launch (k_frame_direct), with the counters, the heavy-first wave order and the
+// per-light luminosities in the per-GPU `scratch` array instead of the scene handle's grow-only buffers.  No hipMalloc,
+// hipFree, event or stream creation anywhere below.  Every call on a GPU uses that GPU's one array: calls that overlap
+// on one GPU race; what must start at zero (the counters) is cleared on the stream first.
+extern "C" int rt_hip_render_whitted_noalloc(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *d_rgb,
+                                              int32_t *d_prim_id, void *stream)
+{
+  RenderArgs A; int rc = fill_args(s, cam, P, &A); if (rc) return rc;
+  if (!d_rgb) return fail(RT_HIP_EINVAL, "rgb is NULL");
+  if (A.cam.depth > 1) return fail(RT_HIP_EUNSUPPORTED, "rt_hip_render_whitted_noalloc: camera depth must be 1 (deeper ray trees need level arrays that grow with the frame)");
+  if (s->dev.n_lights <= 0) return fail(RT_HIP_EUNSUPPORTED, "rt_hip_render_whitted_noalloc: the scene needs at least one light");
+  const int device = s->ctx->device;
+  if (device < 0 || device >= RT_MAX_DEVICES || !g_scratch_ptr[device]) return fail(RT_HIP_EUNSUPPORTED, "rt_hip_render_whitted_noalloc: no scratch array on this device");
+  HIP_TRY(hipSetDevice(device));
+  unsigned char *ptr = g_scratch_ptr[device];          // this GPU's copy of `scratch`
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t n_waves = level0_waves(A), n0 = n_waves * 64;
+  if (A.pixel_count == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
+  // layout: [0, 256) counters | wave order workspace | luminosities (only for scenes that are not one light of one sample)
+  const size_t ord_b = s->dev.has_tree ? ((order_bytes(n_waves) + 255) & ~(size_t)255) : 0;
+  const size_t lum_b = s->one_sample ? 0 : (size_t)n0 * s->dev.n_lights * sizeof(double);
+  const size_t need = 256 + ord_b + lum_b;
+  if (need > RT_NOALLOC_SCRATCH_BYTES)
+    return fail(RT_HIP_EINVAL, "rt_hip_render_whitted_noalloc: frame needs " + std::to_string(need) + " bytes of scratch, the fixed array holds " +
+                                   std::to_string((size_t)RT_NOALLOC_SCRATCH_BYTES) + " (use rt_hip_render_whitted_dev, or shard the pixels)");
+  RenderCounters *cnt = (RenderCounters *)ptr;
+  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(RenderCounters), st));
+  s->last_rays = 0; s->last_shadow = 0; s->last_counters = cnt;
+  OrderBufs O;
+  if (s->dev.has_tree) { rc = order_waves(s, A, n_waves, ptr + 256, st, O, false); if (rc) return rc; }
+  return launch_frame_direct(s, A, P->collect_stats != 0, st, n_waves, O.order0, (double *)(ptr + 256 + ord_b), cnt, d_rgb, d_prim_id, false);
 }
 
 // Camera.h:187-192 for the sample shard [s_first, s_first + s_count) of spp: sum of sample / spp into d_rgb
@@ -1577,7 +1659,7 @@ extern "C" int rt_hip_render_focusing_dev(rt_hip_scene *s, const rt_hip_camera *
   A.focusing = 1; A.lens_radius = P->lens_radius;
   rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
-  s->last_rays = 0; s->last_shadow = 0;
+  s->last_rays = 0; s->last_shadow = 0; s->last_counters = s->counter.p;
   return focusing_batches(s, A, P->collect_stats != 0, spp, s_first, s_count, d_rgb, st);
 }
 
@@ -1609,7 +1691,8 @@ extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *
   HIP_TRY(hipSetDevice(s->ctx->device));
   HIP_TRY(hipDeviceSynchronize());
   RenderCounters c{};
-  if (s->counter.p) HIP_TRY(hipMemcpy(&c, s->counter.p, sizeof c, hipMemcpyDeviceToHost));
+  const void *src = s->last_counters ? s->last_counters : s->counter.p;
+  if (src) HIP_TRY(hipMemcpy(&c, src, sizeof c, hipMemcpyDeviceToHost));
   if (rays) *rays = s->last_rays + c.shadow_rays;
   if (shadow_rays) *shadow_rays = c.shadow_rays;
   return RT_HIP_OK;
