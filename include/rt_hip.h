@@ -148,8 +148,19 @@ typedef struct {
   uint32_t sample_first;    /* shard of the spp loop; sample_count 0 = all */
   uint32_t sample_count;
   uint32_t collect_stats;   /* non-zero: count node visits / primitive tests (slower kernels) */
-  uint32_t reserved;
+  /* Interleaved tile shard of the pixel loop of Camera.h:59-63 (rt_hip_render_whitted only): the image is cut into
+   * super-tiles of 128 x 64 pixels, numbered row-major ((W+127)/128 per row); with tile_stride = N > 1 the call renders
+   * super-tiles tile_offset, tile_offset + N, ... -- every rank's share is spread over the whole image, so the shares cost
+   * the same (a contiguous eighth of BASELINE's C2 frame costs up to 1.8x the average).  The outputs then hold the call's
+   * super-tiles one after the other, 128 x 64 entries each, row-major inside the tile; entries that fall outside the
+   * image are not written.  rt_hip_tile_shard_info gives the sizes, rt_hip_tiles_to_frame_dev turns the all-gathered
+   * shards of all ranks back into the raster frame.  0 or 1 = no tile shard.  Excludes pixel_count. */
+  uint32_t tile_offset;
+  uint32_t tile_stride;
+  uint32_t frame_format;    /* RT_HIP_FRAME_*: what the rgb argument of rt_hip_render_whitted(_dev / _noalloc) receives */
 } rt_hip_params;
+#define RT_HIP_FRAME_RGB_F64 0u   /* 3 doubles R,G,B per pixel: CColour before the store of Camera.h:69 (default) */
+#define RT_HIP_FRAME_BGR8    1u   /* 3 bytes B,G,R per pixel: the Vec3b picture after (uchar) truncation, Camera.h:69 */
 
 typedef struct {
   uint64_t rays;            /* closest-hit + occlusion queries */
@@ -236,6 +247,17 @@ int rt_hip_render_whitted_dev(rt_hip_scene *scene, const rt_hip_camera *cam, con
 int rt_hip_render_whitted_noalloc(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
                                   double *d_rgb, int32_t *d_prim_id, void *stream);
 
+/* Sizes of a tile shard (rt_hip_params.tile_stride): super-tiles of the camera's image, super-tiles per rank
+ * (= ceil(total / tile_stride): every rank's output arrays hold that many x 8192 entries, so that the shards all-gather
+ * with equal counts; a rank whose last slot has no super-tile leaves it unwritten). */
+int rt_hip_tile_shard_info(const rt_hip_camera *cam, uint32_t tile_stride, uint32_t *super_tiles, uint32_t *per_rank);
+/* The all-gathered shards (rank r's per_rank x 8192 entries at d_tiles + r * rank_pitch_bytes; 0 = tightly packed,
+ * per_rank * 8192 * elem_bytes; a larger pitch when every rank contributed several frames to one all-gather) -> the
+ * raster frame d_frame[v*W+h]; elem_bytes = 24 (f64 R,G,B), 3 (B,G,R bytes), 4 (prim ids) or any other entry size.
+ * This is the store picture.at<Vec3b>(v,h) of Camera.h:69 for tiles rendered elsewhere. */
+int rt_hip_tiles_to_frame_dev(const rt_hip_camera *cam, uint32_t tile_stride, const void *d_tiles, uint64_t rank_pitch_bytes,
+                              uint32_t elem_bytes, void *d_frame, void *stream);
+
 /* CCamera::Render_Focusing (Camera.h:171-199): spp lens samples per pixel.  The output is the SUM over
  * the sample shard of sample_colour/spp WITHOUT the running clamp, so that shards add up
  * (all-reduce) and one final min(255, .) gives the reference's clamped running sum (every term
@@ -315,6 +337,24 @@ int rt_hip_render_godray(rt_hip_scene *scene, rt_hip_godray *g, const rt_hip_cam
 int rt_hip_render_godray_dev(rt_hip_scene *scene, rt_hip_godray *g, const rt_hip_camera *cam, const rt_hip_params *params, double *d_rgb,
                              int32_t *d_prim_id, void *stream);
 int rt_hip_godray_destroy(rt_hip_godray *g);
+
+/* ---- multi-GPU exchange: one process per GPU, RCCL over xGMI behind the ABI.  The reference has no counterpart: its only
+ * parallelism is the OpenMP pixel loop of Camera.h:59-63, which these calls let a host shard over GPUs without Python --
+ * tiles of the picture are all-gathered (rt_hip_params.tile_offset / tile_stride), sample sums of Render_Focusing
+ * (Camera.h:191) and the photon statistics of a pass (PhotonMapper.h:334-355) are all-reduced.  Rank 0 makes the id
+ * (ncclGetUniqueId) and the launcher hands its bytes to the other ranks (a file, a socket, torch.distributed's store);
+ * every rank then calls rt_hip_comm_create (ncclCommInitRank: collective, blocks until all ranks have called).  RCCL is
+ * loaded at run time when a communicator of more than one rank is first made; world == 1 needs neither RCCL nor an id
+ * (all_gather copies, all_reduce does nothing; with RT_HIP_COMM_FORCE_RCCL=1 in the environment -- a test aid -- a
+ * one-rank communicator goes through RCCL as well).  Collectives are enqueued on `stream` and return. ---- */
+#define RT_HIP_COMM_ID_BYTES 128
+typedef struct rt_hip_comm rt_hip_comm;
+int rt_hip_comm_unique_id(unsigned char *id /* RT_HIP_COMM_ID_BYTES */);
+int rt_hip_comm_create(rt_hip_ctx *ctx, const unsigned char *id, int rank, int world, rt_hip_comm **out);
+int rt_hip_comm_info(rt_hip_comm *comm, int *rank, int *world);
+int rt_hip_comm_all_gather(rt_hip_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+int rt_hip_comm_all_reduce_sum_f64(rt_hip_comm *comm, double *d_buf, size_t n, void *stream);
+int rt_hip_comm_destroy(rt_hip_comm *comm);
 
 /* Per-kernel device time, measured with hipEvents recorded on the caller's stream around every
  * kernel launch of this scene while profiling is on (rt_hip_set_profiling).  Index = RT_HIP_K_*. */

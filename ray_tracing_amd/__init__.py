@@ -45,7 +45,8 @@ class CameraStruct(C.Structure):
 class Params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("background", d3), ("weight_threshold", C.c_double), ("seed", C.c_uint64),
                 ("spp", C.c_uint32), ("lens_radius", C.c_double), ("pixel_first", C.c_uint64), ("pixel_count", C.c_uint64),
-                ("sample_first", C.c_uint32), ("sample_count", C.c_uint32), ("collect_stats", C.c_uint32), ("reserved", C.c_uint32)]
+                ("sample_first", C.c_uint32), ("sample_count", C.c_uint32), ("collect_stats", C.c_uint32), ("tile_offset", C.c_uint32),
+                ("tile_stride", C.c_uint32), ("frame_format", C.c_uint32)]
 
     def __init__(self, background=(0, 0, 0), seed=0, **kw):
         super().__init__()
@@ -152,6 +153,14 @@ hip.rt_hip_camera_size.argtypes = [C.POINTER(CameraStruct), C.POINTER(C.c_int), 
 hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
 hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_render_whitted_noalloc.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
+hip.rt_hip_tile_shard_info.argtypes = [C.POINTER(CameraStruct), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+hip.rt_hip_tiles_to_frame_dev.argtypes = [C.POINTER(CameraStruct), C.c_uint32, _vp, C.c_uint64, C.c_uint32, _vp, _vp]
+hip.rt_hip_comm_unique_id.argtypes = [_vp]
+hip.rt_hip_comm_create.argtypes = [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]
+hip.rt_hip_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+hip.rt_hip_comm_all_gather.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp]
+hip.rt_hip_comm_all_reduce_sum_f64.argtypes = [_vp, _vp, C.c_size_t, _vp]
+hip.rt_hip_comm_destroy.argtypes = [_vp]
 hip.rt_hip_render_focusing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp]
 hip.rt_hip_render_focusing_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
 hip.rt_hip_render_antialiasing.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.POINTER(AaParams), _vp, _vp]

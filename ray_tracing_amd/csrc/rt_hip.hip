@@ -570,6 +570,11 @@ struct RenderArgs {
   uint32_t v_lo, tiles_x, tiles_y;   // 8x8 tiling of the rows that hold the shard
   uint32_t sample_first, n_samples;   // samples handled by this launch
   double lens_radius; int focusing;
+  // interleaved shard of the 128x64-pixel super-tiles (rt_hip_params.tile_offset / tile_stride): this call renders the
+  // super-tiles tile_offset, tile_offset + tile_stride, ... (n_st of them) and its outputs hold them one after the other
+  uint32_t tile_offset, tile_stride, n_st;
+  uint32_t out_bgr8;                  // the frame goes out as the reference's Vec3b picture (Camera.h:69) instead of f64 R,G,B
+  uint64_t n_out, n_primary;          // entries of the output arrays; camera rays of this call
 };
 
 // ---- heavy-first work order --------------------------------------------------------------------
@@ -586,11 +591,32 @@ __device__ __forceinline__ bool ray_meets_box(V3 o, V3 d, const double *bmin, co
 
 __device__ __forceinline__ void tile_of_wave(const RenderArgs &A, unsigned int wave, unsigned int &s_local, unsigned int &tx, unsigned int &ty)
 {
-  const unsigned int sx = (A.tiles_x + 15) / 16, sy = (A.tiles_y + 7) / 8;
-  const unsigned int per_sample = sx * sy * 128;
+  const unsigned int sx = (A.tiles_x + 15) / 16;
+  const unsigned int per_sample = A.n_st * 128;
   s_local = wave / per_sample;
-  const unsigned int wi = wave % per_sample, st_i = wi / 128, in_st = wi % 128;
+  const unsigned int wi = wave % per_sample, st_i = A.tile_offset + (wi / 128) * A.tile_stride, in_st = wi % 128;
   tx = (st_i % sx) * 16 + (in_st % 16); ty = (st_i / sx) * 8 + (in_st / 16);
+}
+// where pixel (h, v) goes in the output arrays: raster order relative to the pixel shard, or -- with a tile shard -- the
+// call's super-tiles one after the other, 128 x 64 entries each in row-major order (entries outside the image stay unwritten)
+__device__ __forceinline__ uint64_t out_slot(const RenderArgs &A, unsigned int h, unsigned int v)
+{
+  if (A.tile_stride > 1) {
+    const unsigned int sx = (A.tiles_x + 15) / 16;
+    const unsigned int st_local = ((v / 64) * sx + h / 128 - A.tile_offset) / A.tile_stride;
+    return (uint64_t)st_local * 8192 + (v % 64) * 128 + (h % 128);
+  }
+  return (uint64_t)v * A.cam.W + h - A.pixel_first;
+}
+// Camera.h:69: picture.at<Vec3b>(v, h) = (uchar)B, (uchar)G, (uchar)R -- or the doubles before that store
+__device__ __forceinline__ void store_colour(const RenderArgs &A, double *rgb, uint64_t q, Col c, bool stream_out)
+{
+  if (A.out_bgr8) {
+    unsigned char *o = (unsigned char *)rgb + 3 * q;
+    o[0] = (unsigned char)(int)c.b; o[1] = (unsigned char)(int)c.g; o[2] = (unsigned char)(int)c.r;
+  } else if (stream_out) {
+    __builtin_nontemporal_store(c.r, &rgb[3 * q]); __builtin_nontemporal_store(c.g, &rgb[3 * q + 1]); __builtin_nontemporal_store(c.b, &rgb[3 * q + 2]);
+  } else { rgb[3 * q] = c.r; rgb[3 * q + 1] = c.g; rgb[3 * q + 2] = c.b; }
 }
 
 // one thread per wave of k_primary: heavy iff one of the tile's corner rays meets the root box
@@ -772,8 +798,8 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
       c = local_illumination<PARAM>(sc, d, id, pt, ONE ? &l_one : lum + ((size_t)wave * 64 + lane) * nl, N, hu, hv);
     }
     // the frame is written once and read by nobody on this GPU: streamed past the L2 lines that hold the hierarchy
-    const uint64_t q = (uint64_t)pix - A.pixel_first;
-    __builtin_nontemporal_store(c.r, &rgb[3 * q]); __builtin_nontemporal_store(c.g, &rgb[3 * q + 1]); __builtin_nontemporal_store(c.b, &rgb[3 * q + 2]);
+    const uint64_t q = out_slot(A, pix % (unsigned)A.cam.W, pix / (unsigned)A.cam.W);
+    store_colour(A, rgb, q, c, true);
     if (prim_id) __builtin_nontemporal_store(id, &prim_id[q]);
   }
   // shadow rays of this wave: the count per shaded point does not depend on the walks
@@ -792,9 +818,9 @@ __device__ __forceinline__ uint64_t node_of_pixel(const RenderArgs &A, uint64_t 
 {
   const unsigned int h = (unsigned int)(p % A.cam.W), v = (unsigned int)(p / A.cam.W) - A.v_lo;
   const unsigned int tx = h / 8, ty = v / 8;
-  const unsigned int sx = (A.tiles_x + 15) / 16, sy = (A.tiles_y + 7) / 8;
-  const unsigned int st_i = (ty / 8) * sx + tx / 16, in_st = (ty % 8) * 16 + (tx % 16);
-  const uint64_t wave = (uint64_t)s_local * (sx * sy * 128) + (uint64_t)st_i * 128 + in_st;
+  const unsigned int sx = (A.tiles_x + 15) / 16;
+  const unsigned int st_local = ((ty / 8) * sx + tx / 16 - A.tile_offset) / A.tile_stride, in_st = (ty % 8) * 16 + (tx % 16);
+  const uint64_t wave = (uint64_t)s_local * (A.n_st * 128) + (uint64_t)st_local * 128 + in_st;
   return wave * 64 + (v % 8) * 8 + (h % 8);
 }
 
@@ -931,8 +957,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, P
   }
   if (direct_rgb) {
     if (in_range && nd.weight > 0.0) {          // padding lanes of edge tiles carry weight 0
-      const uint64_t q = (uint64_t)nd.pixel - A.pixel_first;
-      direct_rgb[3 * q] = c.r; direct_rgb[3 * q + 1] = c.g; direct_rgb[3 * q + 2] = c.b;
+      const uint64_t q = out_slot(A, nd.pixel % (unsigned)A.cam.W, nd.pixel / (unsigned)A.cam.W);
+      store_colour(A, direct_rgb, q, c, false);
       if (direct_id) direct_id[q] = nd.id;
     }
     return;
@@ -959,25 +985,50 @@ __global__ void __launch_bounds__(RT_BLOCK) k_combine(PathNode *nodes, unsigned 
   w.col[0] = c.r; w.col[1] = c.g; w.col[2] = c.b;
 }
 
-// Camera.h:69 up to the uchar store / Camera.h:191 accumulation over the samples of this launch
+// Camera.h:69 up to (out_bgr8: including) the uchar store / Camera.h:191 accumulation over the samples of this launch
 __global__ void __launch_bounds__(RT_BLOCK) k_resolve(const PathNode *nodes, RenderArgs A, double spp, int accumulate,
                                                       double *rgb, int32_t *prim_id)
 {
   const uint64_t q = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
-  if (q >= A.pixel_count) return;
+  if (q >= A.n_out) return;
+  uint64_t p = A.pixel_first + q;                   // raster pixel of output entry q
+  if (A.tile_stride > 1) {
+    const unsigned int sx = (A.tiles_x + 15) / 16;
+    const unsigned int st_i = A.tile_offset + (unsigned int)(q / 8192) * A.tile_stride, r = (unsigned int)(q % 8192);
+    const unsigned int h = (st_i % sx) * 128 + r % 128, v = (st_i / sx) * 64 + r / 128;
+    if (h >= (unsigned)A.cam.W || v >= (unsigned)A.cam.H) return;       // padding of an edge super-tile
+    p = (uint64_t)v * A.cam.W + h;
+  }
   if (!A.focusing) {
-    const PathNode &w = nodes[node_of_pixel(A, A.pixel_first + q, 0)];
-    rgb[3 * q] = w.col[0]; rgb[3 * q + 1] = w.col[1]; rgb[3 * q + 2] = w.col[2];
+    const PathNode &w = nodes[node_of_pixel(A, p, 0)];
+    store_colour(A, rgb, q, mkc(w.col[0], w.col[1], w.col[2]), false);
     if (prim_id) prim_id[q] = w.id;
     return;
   }
   double r = accumulate ? rgb[3 * q] : 0.0, g = accumulate ? rgb[3 * q + 1] : 0.0, b = accumulate ? rgb[3 * q + 2] : 0.0;
   for (uint32_t s = 0; s < A.n_samples; s++) {
-    const PathNode &w = nodes[node_of_pixel(A, A.pixel_first + q, s)];
+    const PathNode &w = nodes[node_of_pixel(A, p, s)];
     Col c = cdiv(mkc(w.col[0], w.col[1], w.col[2]), spp);   // RayTracer(...) / sampleTimes
     r += c.r; g += c.g; b += c.b;
   }
   rgb[3 * q] = r; rgb[3 * q + 1] = g; rgb[3 * q + 2] = b;
+}
+
+// rt_hip_tiles_to_frame_dev: the all-gathered tile shards (rank-major: tile_stride blocks of per_rank super-tiles of
+// 128 x 64 entries) back into the raster frame
+__global__ void __launch_bounds__(256) k_tiles_to_frame(const unsigned char *tiles, unsigned int W, unsigned int H, unsigned int stride, uint64_t rank_pitch,
+                                                        unsigned int elem, unsigned char *frame)
+{
+  const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (uint64_t)W * H) return;
+  const unsigned int h = (unsigned int)(p % W), v = (unsigned int)(p / W);
+  const unsigned int sx = ((W + 7) / 8 + 15) / 16;
+  const unsigned int st_i = (v / 64) * sx + h / 128;
+  const unsigned char *blk = tiles + (uint64_t)(st_i % stride) * rank_pitch;          // the shard of the rank that rendered this super-tile
+  const uint64_t src = (uint64_t)(st_i / stride) * 8192 + (v % 64) * 128 + (h % 128);
+  if (elem == 24) { const double *a = (const double *)blk + 3 * src; double *o = (double *)frame + 3 * p; o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
+  else if (elem == 4) ((unsigned int *)frame)[p] = ((const unsigned int *)blk)[src];
+  else for (unsigned int k = 0; k < elem; k++) frame[p * elem + k] = blk[src * elem + k];
 }
 
 // ================================================================================================
@@ -1513,10 +1564,10 @@ static int launch_frame_direct(rt_hip_scene *s, const RenderArgs &A, bool stats,
   HIP_TRY(hipGetLastError());
   for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) s->last_n_level[lv] = 0;
   s->last_level = 0;
-  s->last_rays += A.pixel_count;
+  s->last_rays += A.n_primary;
   return RT_HIP_OK;
 }
-static inline uint64_t level0_waves(const RenderArgs &A) { return (uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * A.n_samples; }
+static inline uint64_t level0_waves(const RenderArgs &A) { return (uint64_t)A.n_st * 128 * A.n_samples; }
 
 // the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
 static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, double *direct_rgb = nullptr, int32_t *direct_id = nullptr)
@@ -1553,7 +1604,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
     order1 = O.order1;
   }
   HIP_TRY(hipGetLastError());
-  return run_levels_from(s, A, stats, st, n0, order1, A.pixel_count * A.n_samples, direct_rgb, direct_id);
+  return run_levels_from(s, A, stats, st, n0, order1, A.n_primary * A.n_samples, direct_rgb, direct_id);
 }
 
 static int fill_args(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, RenderArgs *A)
@@ -1572,8 +1623,28 @@ static int fill_args(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_par
   const uint32_t v_hi = (uint32_t)((A->pixel_first + A->pixel_count - 1) / A->cam.W);
   A->tiles_x = (uint32_t)(A->cam.W + 7) / 8; A->tiles_y = (v_hi - A->v_lo + 8) / 8;
   A->sample_first = 0; A->n_samples = 1; A->lens_radius = 0; A->focusing = 0;
+  const uint32_t sx = (A->tiles_x + 15) / 16, sy = (A->tiles_y + 7) / 8;
+  A->tile_offset = 0; A->tile_stride = 1; A->n_st = sx * sy; A->n_out = A->pixel_count; A->n_primary = A->pixel_count;
+  A->out_bgr8 = 0;
+  if (P->frame_format != RT_HIP_FRAME_RGB_F64 && P->frame_format != RT_HIP_FRAME_BGR8) return fail(RT_HIP_EINVAL, "rt_hip_params.frame_format unknown");
+  if (P->tile_stride > 1) {
+    if (P->pixel_count) return fail(RT_HIP_EINVAL, "a tile shard (tile_stride > 1) and a pixel shard (pixel_count) exclude each other");
+    if (P->tile_offset >= P->tile_stride) return fail(RT_HIP_EINVAL, "tile_offset must be below tile_stride");
+    A->tile_offset = P->tile_offset; A->tile_stride = P->tile_stride;
+    const uint32_t total = sx * sy;
+    A->n_st = (total > P->tile_offset) ? (total - P->tile_offset + P->tile_stride - 1) / P->tile_stride : 0;
+    A->n_out = (uint64_t)A->n_st * 8192;
+    uint64_t np = 0;                    // pixels of the image inside this call's super-tiles
+    for (uint32_t k = 0; k < A->n_st; k++) {
+      const uint32_t st_i = A->tile_offset + k * A->tile_stride;
+      const int64_t w = std::min<int64_t>(128, (int64_t)A->cam.W - (int64_t)(st_i % sx) * 128), h = std::min<int64_t>(64, (int64_t)A->cam.H - (int64_t)(st_i / sx) * 64);
+      if (w > 0 && h > 0) np += (uint64_t)(w * h);
+    }
+    A->n_primary = np;
+  } else if (P->tile_offset) return fail(RT_HIP_EINVAL, "tile_offset without tile_stride");
   return RT_HIP_OK;
 }
+static bool tile_sharded(const RenderArgs &A) { return A.tile_stride > 1; }
 
 extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *d_rgb,
                                           int32_t *d_prim_id, void *stream)
@@ -1585,11 +1656,13 @@ extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *c
   rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
   s->last_rays = 0; s->last_shadow = 0; s->last_counters = s->counter.p;
+  A.out_bgr8 = (P->frame_format == RT_HIP_FRAME_BGR8) ? 1u : 0u;
+  if (A.n_st == 0) return RT_HIP_OK;        // a tile shard beyond the image's last super-tile: nothing to render
   const bool direct = A.cam.depth <= 1;     // a depth-1 frame is final after level 0: k_shade writes it
   rc = run_levels(s, A, P->collect_stats != 0, st, direct ? d_rgb : nullptr, direct ? d_prim_id : nullptr); if (rc) return rc;
   if (!direct) {
     ProfScope ps(s, RT_HIP_K_RESOLVE, st);
-    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.pixel_count)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, 1.0, 0, d_rgb, d_prim_id);
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.n_out)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, 1.0, 0, d_rgb, d_prim_id);
   }
   HIP_TRY(hipGetLastError());
   return RT_HIP_OK;
@@ -1612,6 +1685,8 @@ extern "C" int rt_hip_render_whitted_noalloc(rt_hip_scene *s, const rt_hip_camer
   HIP_TRY(hipSetDevice(device));
   unsigned char *ptr = g_scratch_ptr[device];          // this GPU's copy of `scratch`
   hipStream_t st = (hipStream_t)stream;
+  A.out_bgr8 = (P->frame_format == RT_HIP_FRAME_BGR8) ? 1u : 0u;
+  if (A.n_st == 0) return RT_HIP_OK;
   const uint64_t n_waves = level0_waves(A), n0 = n_waves * 64;
   if (A.pixel_count == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
   // layout: [0, 256) counters | wave order workspace | luminosities (only for scenes that are not one light of one sample)
@@ -1627,6 +1702,32 @@ extern "C" int rt_hip_render_whitted_noalloc(rt_hip_scene *s, const rt_hip_camer
   OrderBufs O;
   if (s->dev.has_tree) { rc = order_waves(s, A, n_waves, ptr + 256, st, O, false); if (rc) return rc; }
   return launch_frame_direct(s, A, P->collect_stats != 0, st, n_waves, O.order0, (double *)(ptr + 256 + ord_b), cnt, d_rgb, d_prim_id, false);
+}
+
+extern "C" int rt_hip_tile_shard_info(const rt_hip_camera *cam, uint32_t tile_stride, uint32_t *super_tiles, uint32_t *per_rank)
+{
+  DevCamera k; int rc = camera_setup(cam, &k); if (rc) return rc;
+  if (tile_stride == 0) tile_stride = 1;
+  const uint32_t sx = (((uint32_t)k.W + 7) / 8 + 15) / 16, sy = (((uint32_t)k.H + 7) / 8 + 7) / 8;
+  if (super_tiles) *super_tiles = sx * sy;
+  if (per_rank) *per_rank = (sx * sy + tile_stride - 1) / tile_stride;
+  return RT_HIP_OK;
+}
+extern "C" int rt_hip_tiles_to_frame_dev(const rt_hip_camera *cam, uint32_t tile_stride, const void *d_tiles, uint64_t rank_pitch_bytes, uint32_t elem_bytes,
+                                         void *d_frame, void *stream)
+{
+  DevCamera k; int rc = camera_setup(cam, &k); if (rc) return rc;
+  if (!d_tiles || !d_frame || elem_bytes == 0 || elem_bytes > 256) return fail(RT_HIP_EINVAL, "rt_hip_tiles_to_frame_dev: bad argument");
+  if (tile_stride == 0) tile_stride = 1;
+  uint32_t total = 0, per_rank = 0;
+  rc = rt_hip_tile_shard_info(cam, tile_stride, &total, &per_rank); if (rc) return rc;
+  const uint64_t npix = (uint64_t)k.W * k.H, shard = (uint64_t)per_rank * 8192 * elem_bytes;
+  if (rank_pitch_bytes == 0) rank_pitch_bytes = shard;
+  if (rank_pitch_bytes < shard || (elem_bytes % 4 == 0 && rank_pitch_bytes % 8)) return fail(RT_HIP_EINVAL, "rt_hip_tiles_to_frame_dev: rank_pitch_bytes too small or misaligned");
+  hipLaunchKernelGGL(k_tiles_to_frame, dim3((unsigned int)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)d_tiles,
+                     (unsigned int)k.W, (unsigned int)k.H, tile_stride, rank_pitch_bytes, elem_bytes, (unsigned char *)d_frame);
+  HIP_TRY(hipGetLastError());
+  return RT_HIP_OK;
 }
 
 // Camera.h:187-192 for the sample shard [s_first, s_first + s_count) of spp: sum of sample / spp into d_rgb
@@ -1656,6 +1757,7 @@ extern "C" int rt_hip_render_focusing_dev(rt_hip_scene *s, const rt_hip_camera *
   const uint32_t spp = P->spp ? P->spp : 100;       // Camera.h:171
   uint32_t s_first = P->sample_count ? P->sample_first : 0, s_count = P->sample_count ? P->sample_count : spp;
   if (s_first >= spp || s_count > spp - s_first) return fail(RT_HIP_EINVAL, "sample shard outside [0, spp)");
+  if (tile_sharded(A) || P->frame_format != RT_HIP_FRAME_RGB_F64) return fail(RT_HIP_EUNSUPPORTED, "Render_Focusing shards by samples or pixel ranges and returns f64 sums (tile shards / BGR8 frames: rt_hip_render_whitted)");
   A.focusing = 1; A.lens_radius = P->lens_radius;
   rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
   HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
@@ -1668,8 +1770,11 @@ static int render_host(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_p
   RenderArgs A; int rc = fill_args(s, cam, P, &A); if (rc) return rc;
   if (!rgb) return fail(RT_HIP_EINVAL, "rgb is NULL");
   HIP_TRY(hipSetDevice(s->ctx->device));
-  size_t cb = A.pixel_count * 24, ib = A.pixel_count * 4;
+  size_t cb = A.n_out * ((!focusing && P->frame_format == RT_HIP_FRAME_BGR8) ? 3 : 24), ib = A.n_out * 4;
+  cb = (cb + 255) & ~(size_t)255;
+  if (A.n_out == 0) return RT_HIP_OK;
   rc = s->staging.ensure(cb + ib); if (rc) return rc;
+  if (tile_sharded(A)) HIP_TRY(hipMemset(s->staging.p, 0, cb + ib));          // entries of edge super-tiles outside the image
   double *d_rgb = (double *)s->staging.p; int32_t *d_id = (int32_t *)((char *)s->staging.p + cb);
   rc = focusing ? rt_hip_render_focusing_dev(s, cam, P, d_rgb, nullptr) : rt_hip_render_whitted_dev(s, cam, P, d_rgb, prim_id ? d_id : nullptr, nullptr);
   if (rc) return rc;
@@ -1701,3 +1806,4 @@ extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *
 #include "rt_aa.inc"
 #include "rt_ppm.inc"
 #include "rt_godray.inc"
+#include "rt_comm.inc"

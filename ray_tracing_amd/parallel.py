@@ -1,8 +1,12 @@
 """Multi-GPU sharding of the render calls: one process per GPU (torch.distributed; backend "nccl" is RCCL
 on ROCm, "gloo" in the CPU tests).  The scene is replicated; a frame is split
 
-  * by image rows (deterministic renders): every rank renders its row block through the ABI's pixel shard
-    (bit-identical to the single-GPU frame) and the blocks are all-gathered;
+  * by interleaved tiles (deterministic renders, the default): rank r renders the 128x64-pixel super-tiles
+    r, r + N, ... through the ABI's tile shard (rt_hip_params.tile_offset / tile_stride), so every rank's share is
+    spread over the whole image and costs the same; the shards are all-gathered and rt_hip_tiles_to_frame_dev puts
+    them back into raster order: bit-identical to the single-GPU frame;
+  * by image rows (the anti-aliasing drivers, whose stencil needs neighbouring rows): every rank renders its row
+    block through the ABI's pixel shard (bit-identical to the single-GPU frame) and the blocks are all-gathered;
   * by samples (depth of field / stochastic renders): every rank renders a slice of the spp loop; the ABI
     returns un-clamped sums of sample/spp, which add up under all-reduce(sum); min(255, .) once at the end
     equals the reference's running clamp (Colour.h:41-47) because every term is >= 0.
@@ -134,3 +138,81 @@ def render_focusing_samples(rta, ctx, scene, camera, radius, spp, background=(0,
         rta.check(rta.hip.rt_hip_render_focusing_dev(scene.device(ctx), camera.raw, p, C.c_void_p(acc.data_ptr()),
                                                      C.c_void_p(s.cuda_stream)))
     return reduce_samples(acc, group)
+
+
+# ---- interleaved tile shards (rt_hip_params.tile_offset / tile_stride) ----------------------------------------------
+SUPER_W, SUPER_H = 128, 64            # one super-tile: 16 x 8 tiles of 8 x 8 pixels = 128 waves
+
+
+def tile_shard_counts(width, height, world):
+    """(super-tiles of the image, super-tiles per rank): the arithmetic of rt_hip_tile_shard_info"""
+    sx = ((width + 7) // 8 + 15) // 16
+    sy = ((height + 7) // 8 + 7) // 8
+    return sx * sy, (sx * sy + world - 1) // world
+
+
+def tiles_of_rank(width, height, rank, world):
+    """global super-tile indices rendered by `rank`"""
+    total, _ = tile_shard_counts(width, height, world)
+    return list(range(rank, total, world))
+
+
+def tiles_to_frame_host(tiles, width, height, world):
+    """numpy model of rt_hip_tiles_to_frame_dev: tiles of shape (rank, slot, 64, 128, ...) -> frame (height, width, ...)"""
+    import numpy as np
+    total, per = tile_shard_counts(width, height, world)
+    sx = ((width + 7) // 8 + 15) // 16
+    t = np.asarray(tiles)
+    assert t.shape[:4] == (world, per, SUPER_H, SUPER_W)
+    frame = np.zeros((height, width) + t.shape[4:], dtype=t.dtype)
+    for st in range(total):
+        x0, y0 = (st % sx) * SUPER_W, (st // sx) * SUPER_H
+        w, h = min(SUPER_W, width - x0), min(SUPER_H, height - y0)
+        if w > 0 and h > 0:
+            frame[y0:y0 + h, x0:x0 + w] = t[st % world, st // world, :h, :w]
+    return frame
+
+
+def render_whitted_tiles(rta, ctx, scene, camera, rank, world, background=(0, 0, 0), bgr8=False, out=None, ids=None, stream=None, raw_scene=None):
+    """this rank's interleaved tile shard of Render_RayTracer: (per_rank * 8192, 3) f64 R,G,B -- or uint8 B,G,R with bgr8 --
+    in the ABI's tile order, zero where a super-tile sticks out of the image; enqueued on `stream`"""
+    import torch
+    _, per = tile_shard_counts(camera.width, camera.height, world)
+    if out is None:
+        out = torch.zeros((per * 8192, 3), dtype=torch.uint8 if bgr8 else torch.float64, device="cuda")
+    p = rta.Params(background=background, tile_offset=rank, tile_stride=world, frame_format=1 if bgr8 else 0)
+    s = stream if stream is not None else torch.cuda.current_stream()
+    rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene if raw_scene is not None else scene.device(ctx), camera.raw, p, C.c_void_p(out.data_ptr()),
+                                                C.c_void_p(ids.data_ptr()) if ids is not None else None, C.c_void_p(s.cuda_stream)))
+    return out
+
+
+def gather_tiles(local, group=None):
+    """all-gather of the equally sized tile shards: (world * per_rank * 8192, channels), rank-major"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    return full
+
+
+def tiles_to_frame(rta, camera, world, tiles, frame=None, stream=None, rank_pitch_bytes=0):
+    """rt_hip_tiles_to_frame_dev on device tensors: the gathered shards back into the (H * W, channels) raster frame"""
+    import torch
+    ch = tiles.shape[1] if tiles.dim() > 1 else 1
+    if frame is None:
+        frame = torch.empty((camera.height * camera.width, ch) if ch > 1 else (camera.height * camera.width,), dtype=tiles.dtype, device=tiles.device)
+    s = stream if stream is not None else torch.cuda.current_stream()
+    rta.check(rta.hip.rt_hip_tiles_to_frame_dev(camera.raw, world, C.c_void_p(tiles.data_ptr()), rank_pitch_bytes, tiles.element_size() * ch,
+                                                C.c_void_p(frame.data_ptr()), C.c_void_p(s.cuda_stream)))
+    return frame
+
+
+def render_whitted_tile_split(rta, ctx, scene, camera, background=(0, 0, 0), bgr8=False, group=None):
+    """Render_RayTracer over the ranks of `group` by interleaved tiles + all-gather; the full raster frame on every rank"""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    local = render_whitted_tiles(rta, ctx, scene, camera, rank, world, background, bgr8)
+    return tiles_to_frame(rta, camera, world, gather_tiles(local, group))

@@ -1,0 +1,140 @@
+"""Interleaved tile shards (rt_hip_params.tile_offset / tile_stride), the BGR8 frame (Camera.h:69), the communicator
+behind the ABI (rt_hip_comm_*) and one frame rendered by TWO processes: every form of the multi-GPU split against the
+one-rank result.  Bars: tile split bit-identical, sample split <= 1e-12, photon split exact."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _full_frame(rta, ctx, g, cam, fmt=0, background=(200, 200, 200)):
+    import torch
+    n = cam.width * cam.height
+    rgb = torch.zeros((n, 3), dtype=torch.uint8 if fmt else torch.float64, device="cuda")
+    ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+    p = rta.Params(background=background, frame_format=fmt)
+    rta.check(rta.hip.rt_hip_render_whitted_dev(g.device(ctx), cam.raw, p, C.c_void_p(rgb.data_ptr()), C.c_void_p(ids.data_ptr()), None))
+    torch.cuda.synchronize()
+    return rgb.cpu().numpy(), ids.cpu().numpy()
+
+
+@pytest.mark.parametrize("depth,stride", [(1, 3), (1, 8), (3, 2), (3, 5)])
+def test_tile_shards_reassemble(ctx, depth, stride):
+    """every rank's shard rendered in turn on the one GPU; the reassembled frame equals the one-call frame bit for bit,
+    for the one-launch depth-1 frame and for the wavefront levels, as f64 R,G,B and as the Vec3b picture"""
+    import torch
+    import ray_tracing_amd as rta
+    from ray_tracing_amd import parallel
+    g, _ = scenes.build_icosahedron(material="metal", light="point_area", extra_sphere=True, oracle=False)
+    cam = rta.Camera(**dict(scenes.C1_CAMERA, hor=4.1, ver=2.9, res=100, depth=depth))        # 410 x 290: ragged super-tiles
+    total, per = C.c_uint32(), C.c_uint32()
+    rta.check(rta.hip.rt_hip_tile_shard_info(cam.raw, stride, C.byref(total), C.byref(per)))
+    assert (total.value, per.value) == parallel.tile_shard_counts(cam.width, cam.height, stride) == (4 * 5, (20 + stride - 1) // stride)
+    ref, ref_ids = _full_frame(rta, ctx, g, cam)
+    ref8, _ = _full_frame(rta, ctx, g, cam, fmt=1)
+    assert (ref8[:, ::-1] == ref.astype(np.uint8)).all()            # (uchar)B,(uchar)G,(uchar)R: truncation of the doubles
+    rays_total = 0
+    for bgr8 in (False, True):
+        shards, idsh = [], []
+        for r in range(stride):
+            ids = torch.full((per.value * 8192,), -9, dtype=torch.int32, device="cuda")
+            shards.append(parallel.render_whitted_tiles(rta, ctx, g, cam, r, stride, (200, 200, 200), bgr8=bgr8, ids=ids))
+            idsh.append(ids)
+            if not bgr8:
+                a, b = C.c_uint64(), C.c_uint64()
+                rta.check(rta.hip.rt_hip_last_ray_count(g.device(ctx), C.byref(a), C.byref(b)))
+                rays_total += a.value
+        tiles = torch.cat(shards)
+        frame = parallel.tiles_to_frame(rta, cam, stride, tiles).cpu().numpy()
+        assert np.array_equal(frame, ref8 if bgr8 else ref)
+        assert np.array_equal(parallel.tiles_to_frame(rta, cam, stride, torch.cat(idsh)).cpu().numpy(), ref_ids)
+        # the numpy model of the layout (used by the CPU two-rank test) agrees with the device kernel
+        host = parallel.tiles_to_frame_host(tiles.cpu().numpy().reshape(stride, per.value, 64, 128, 3), cam.width, cam.height, stride)
+        assert np.array_equal(host.reshape(-1, 3), frame)
+    _full_frame(rta, ctx, g, cam)
+    a, b = C.c_uint64(), C.c_uint64()
+    rta.check(rta.hip.rt_hip_last_ray_count(g.device(ctx), C.byref(a), C.byref(b)))
+    assert rays_total == a.value                                       # the shards' ray census adds up to the frame's
+
+
+def test_tile_shard_argument_checks(ctx):
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(oracle=False)
+    cam = rta.Camera(**scenes.C1_CAMERA)
+    bad = [rta.Params(tile_offset=2, tile_stride=2), rta.Params(tile_offset=1), rta.Params(tile_stride=2, pixel_first=0, pixel_count=640),
+           rta.Params(frame_format=7)]
+    for p in bad:
+        assert rta.hip.rt_hip_render_whitted_dev(g.device(ctx), cam.raw, p, C.c_void_p(8), None, None) == -1
+    assert rta.hip.rt_hip_render_focusing_dev(g.device(ctx), cam.raw, rta.Params(tile_stride=2), C.c_void_p(8), None) == -4
+
+
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_comm_one_rank(ctx, force_rccl, monkeypatch):
+    """rt_hip_comm_* with one rank: the plain short cut, and (RT_HIP_COMM_FORCE_RCCL=1) the same calls through RCCL --
+    the run-time binding, ncclGetUniqueId / ncclCommInitRank with the id passed by value, all-gather and all-reduce"""
+    import torch
+    import ray_tracing_amd as rta
+    if force_rccl:
+        monkeypatch.setenv("RT_HIP_COMM_FORCE_RCCL", "1")
+    else:
+        monkeypatch.delenv("RT_HIP_COMM_FORCE_RCCL", raising=False)
+    ident = (C.c_ubyte * 128)()
+    if force_rccl:
+        rta.check(rta.hip.rt_hip_comm_unique_id(ident))
+    comm = C.c_void_p()
+    rta.check(rta.hip.rt_hip_comm_create(ctx.raw, ident if force_rccl else None, 0, 1, C.byref(comm)))
+    r, w = C.c_int(-1), C.c_int(-1)
+    rta.check(rta.hip.rt_hip_comm_info(comm, C.byref(r), C.byref(w)))
+    assert (r.value, w.value) == (0, 1)
+    src = torch.arange(100000, dtype=torch.float64, device="cuda")
+    dst = torch.zeros_like(src)
+    rta.check(rta.hip.rt_hip_comm_all_gather(comm, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel() * 8, None))
+    rta.check(rta.hip.rt_hip_comm_all_reduce_sum_f64(comm, C.c_void_p(dst.data_ptr()), dst.numel(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    assert rta.hip.rt_hip_comm_create(ctx.raw, None, 0, 2, C.byref(C.c_void_p())) == -1      # several ranks need the id
+    rta.check(rta.hip.rt_hip_comm_destroy(comm))
+
+
+def test_two_processes_render_one_frame(ctx, tmp_path):
+    """two processes (both on the one GPU of the box, gloo on host tensors) render ONE frame / sample set / photon pass
+    between them; compared with the one-rank result"""
+    import torch
+    import torch.multiprocessing as mp
+    import ray_tracing_amd as rta
+    from ray_tracing_amd import parallel
+    import mp_workers
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "two_rank.npz")
+    mp.spawn(mp_workers.render_worker, args=(2, port, out), nprocs=2, join=True)
+    res = np.load(out)
+    g, _ = scenes.build_icosahedron(material="metal", light="point_area", extra_sphere=True, oracle=False)
+    cam = rta.Camera(**dict(scenes.C1_CAMERA, hor=4.1, ver=2.9, res=100, depth=3))
+    ref, ref_ids = _full_frame(rta, ctx, g, cam)
+    ref8, _ = _full_frame(rta, ctx, g, cam, fmt=1)
+    assert np.array_equal(res["tiles_f64"], ref) and np.array_equal(res["tiles_bgr8"], ref8) and np.array_equal(res["tiles_ids"], ref_ids)
+    g2, _ = scenes.build_icosahedron(material="plastic", light="area3", oracle=False)
+    cam2 = rta.Camera(**dict(scenes.C1_CAMERA, hor=1.6, ver=1.2, res=50, depth=1))
+    cam2.set_seed(5)
+    cam2.render_focusing(ctx, g2, 0.1, background=(200, 200, 200), spp=7)
+    err = np.abs(res["dof"] - cam2.rgb()) / np.maximum(1.0, np.abs(cam2.rgb()))
+    print("sample split, two ranks: max rel err %.3g" % err.max())
+    assert err.max() <= 1e-12
+    g3, _ = scenes.build_icosahedron(material="plastic", light="area3", extra_sphere=True, oracle=False)
+    cam3 = rta.Camera(**dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=20, depth=2))
+    pm = rta.PhotonMap(ctx, g3, cam3, photon_num=3000, times=2, seed=3)
+    for t in range(2):
+        pm.run_pass(t)
+    torch.cuda.synchronize()
+    hp = pm.hitpoints()
+    assert np.array_equal(res["ppm_hitpoints"][:, :9], hp[:, :9]) and np.array_equal(res["ppm_hitpoints"][:, 10], hp[:, 10])   # photon counts N: exact
+    assert np.allclose(res["ppm_hitpoints"][:, 9], hp[:, 9], rtol=1e-12, atol=0)                                                # radius R
+    assert np.abs(res["ppm_picture"].astype(int) - pm.picture().astype(int)).max() <= 1
+    info = pm.info()
+    assert tuple(res["ppm_census"]) == (info["photon_segments"], info["photon_hits"])

@@ -23,7 +23,7 @@ def test_abi_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
     import ray_tracing_amd as rta
     assert C.sizeof(rta.CameraStruct) == 104
-    assert C.sizeof(rta.Params) == 96
+    assert C.sizeof(rta.Params) == 104
     assert C.sizeof(rta.Stats) == 64
 
 
