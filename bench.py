@@ -1,291 +1,607 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric (Mrays/s, primary+secondary) on configs[1]:
-synthetic 1,002,528-triangle heightfield + ground plane, primary + shadow ray casting at 1920x1080
-(SURVEY 8d C2), through the rt_hip_* C ABI with every input resident in HBM.
+"""bench.py -- BASELINE.json's metric (Mrays/s, primary+secondary; s/frame at fixed spp) through the rt_hip_* C ABI with
+every input resident in HBM.
 
-A "step" = one full frame: camera-ray generation + closest hit, one shadow query per hit pixel, the local
-illumination and the RGB f64 frame -- for this depth-1 camera all in ONE launch (k_frame_direct; deeper ray trees
-run k_primary / k_shadow / k_shade per level).  `--streams S` (default 2) keeps S
-frames in flight per GPU, frame k on stream k % S with its own rt_hip_scene_share handle: wave costs in
-these kernels differ 50x, and the draining tail of one frame is filled by the next frame's waves.  The time
-per frame with one frame in flight is reported beside it (config.ms_per_frame_one_in_flight).
+Default workload = BASELINE configs[1]: the synthetic 1,002,528-triangle heightfield + ground plane,
+primary + shadow ray casting at 1920x1080.  A STEP = a batch of `--frames-per-step` C2 frames (a camera swinging around
+the C2 view); every frame is camera-ray generation + closest hit, one shadow query per hit pixel, the local illumination
+and the reference's Vec3b picture (Camera.h:69) -- for this depth-1 camera ONE launch (k_frame_direct).  `--streams S`
+keeps S frames in flight per GPU (wave costs differ 50x; the draining tail of one frame is filled by the next).
 
-Multi-GPU (one process per GPU, torchrun): C2 is a deterministic ray cast, so ranks render
-independent frames (rank r renders the camera of frame step*N + r on a small orbit): the path
-partitions by frame, no data-path collective, "scaling": "weak".  `--mode samples` runs the sample-split
-form instead (each rank renders its own jittered sample of ONE frame, RCCL all-reduce(sum) of the
-radiance, overlapped with the next step's render on a second stream).
+N > 1 GPUs (one process per GPU; `python bench.py --gpus N` starts its own ranks through torch.distributed.run, or is
+started by it): the SAME batch of frames per step, every frame split over the ranks by interleaved 128x64-pixel
+super-tiles (rt_hip_params.tile_offset / tile_stride: rank r renders super-tiles r, r+N, ...), the shards all-gathered
+over RCCL (rt_hip_comm_all_gather, or torch.distributed with --comm torch) and put back into raster order on every rank
+(rt_hip_tiles_to_frame_dev); the gather of one sub-batch overlaps the rendering of the next on a second stream.  Total
+work per step is fixed: "scaling": "strong".  `--mode replicas` is the collective-free form (each rank renders its own
+frames, "weak"), kept as a secondary figure.
+
+`--config C3|C4|C5` times the other BASELINE configs (depth of field, Bezier scene, photon mapping) with the same JSON
+shape; a short run of each is folded into the default line as config.other_configs.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-FP64_VALU_PEAK_TF = 78.6   # MI355X vector FP64 (spec, FMA = 2 flop)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64 (FMA = 2 flop): 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz
+N_SIMD = 1024                # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4              # peak engine clock; a wave64 VALU instruction occupies its SIMD for 4 cycles
+VALU_ISSUE_PEAK_G = N_SIMD * CLOCK_GHZ / 4.0      # 614.4 G wave-instructions/s: the roof the walk kernels are bound by
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default="C2")
+    ap.add_argument("--frames-per-step", type=int, default=128, help="C2: frames per step (a step of ~100 ms on one GPU)")
+    ap.add_argument("--sub-batch", type=int, default=16, help="C2, N>1: frames per all-gather")
     ap.add_argument("--cells", type=int, default=708, help="heightfield cells per side (708 -> 1,002,528 triangles)")
     ap.add_argument("--leaf-refine", type=int, default=None, help="rt_hip_scene_create leaf_refine (include/rt_hip.h; default: the library's own hierarchy)")
-    ap.add_argument("--mode", choices=["frames", "samples"], default="frames")
-    ap.add_argument("--streams", type=int, default=2, help="frames in flight per GPU (one scene handle and HIP stream each)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU)")
-    ap.add_argument("--no-profile", action="store_true", help="no per-kernel events inside the timed region (no roofline object)")
+    ap.add_argument("--mode", choices=["tiles", "replicas"], default="tiles")
+    ap.add_argument("--comm", choices=["abi", "torch"], default="abi", help="data-path collective: rt_hip_comm_* (RCCL behind the C ABI) or torch.distributed")
+    ap.add_argument("--streams", type=int, default=0, help="frames in flight per GPU (0 = 2, or 4 from 4 ranks on)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU: collectives then run on HOST tensors)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="one GPU renders rank 0's share of an N-rank run, no collective (tuning aid; not a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame timed on the CPU (0 = auto)")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (reference tree, f64 frame, other configs)")
+    ap.add_argument("--spp", type=int, default=0, help="C3 / C4: samples per pixel timed per step (0 = a short default; the full config is 1024 / 256)")
+    ap.add_argument("--photons", type=int, default=0, help="C5: photons per light sample and pass (0 = a short default; the full config is 400000)")
+    return ap.parse_args()
 
-    import numpy as np
-    import torch
-    import ray_tracing_amd as rta
-    import scenes
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
-    rehearsal = args.backend != "nccl"
-    if rehearsal:
-        local_rank = local_rank % max(1, torch.cuda.device_count())       # every rank on the GPUs that exist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    cdev = torch.device("cpu") if rehearsal else dev                       # where the collectives' tensors live
-    if world > 1:
-        import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group(args.backend)
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+def self_launch(args):
+    """`python bench.py --gpus N` invoked plainly: start N fresh ranks BEFORE anything here touches the GPU (a process that
+    has initialised HIP must never exec), relay their output, return their exit code"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
-    # ---- scene (host: build mesh + BSP; device: upload) ----
+
+# ---------------------------------------------------------------------------------------------------------------------
+class Dist:
+    """rank / world, barrier, small reductions; the data-path collective of the chosen kind"""
+
+    def __init__(self, args, torch):
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.rehearsal = args.backend != "nccl"
+        if self.rehearsal:
+            self.local_rank %= max(1, torch.cuda.device_count())      # every rank on the GPUs that exist
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.cdev = torch.device("cpu") if self.rehearsal else self.dev
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.rehearsal:
+                dist.init_process_group(args.backend)
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, value, op="max"):
+        if self.dist is None:
+            return float(value)
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN, "sum": self.dist.ReduceOp.SUM}[op])
+        return float(t.item())
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def make_abi_comm(rta, ctx, D):
+    """rt_hip_comm over all ranks: rank 0's ncclUniqueId travels through torch.distributed (the launcher's rendezvous).
+    Returns the handle, or None when any rank failed (then every rank falls back to torch's collective)."""
+    torch = D.torch
+    ident = (C.c_ubyte * 128)()
+    ok = 1.0
+    if D.rank == 0 and rta.hip.rt_hip_comm_unique_id(ident) != 0:
+        ok = 0.0
+    t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device=D.cdev)
+    D.dist.broadcast(t, src=0)
+    ident = (C.c_ubyte * 128)(*t.cpu().tolist())
+    comm = C.c_void_p()
+    if D.reduce(ok, "min") < 1.0:
+        return None
+    if rta.hip.rt_hip_comm_create(ctx.raw, ident, D.rank, D.world, C.byref(comm)) != 0:
+        sys.stderr.write("rank %d: rt_hip_comm_create failed: %s\n" % (D.rank, rta.hip.rt_hip_last_error().decode()))
+        ok = 0.0
+    if D.reduce(ok, "min") < 1.0:
+        return None
+    return comm
+
+
+def last_rays(rta, raw):
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    rta.check(rta.hip.rt_hip_last_ray_count(raw, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def read_traffic(kernel):
+    """per-launch PMC figures of `kernel` from the committed rocprofv3 passes (profiles/r02_traffic.json), or {}"""
+    try:
+        return json.load(open(TRAFFIC_FILE)).get(kernel, {})
+    except Exception:
+        return {}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_c2(args, D, torch, rta, W):
+    rank, world, dev = D.rank, D.world, D.dev
     t0 = time.time()
-    ctx = rta.Context(local_rank)
-    gscene, _ = scenes.build_heightfield(args.cells, gpu=True, oracle=False, leaf_refine=args.leaf_refine)
+    ctx = rta.Context(D.local_rank)
+    gscene = W.build_heightfield(W.product_stage, args.cells, leaf_refine=args.leaf_refine).sides[0][0]
     raw_scene = gscene.device(ctx)
     n_tris = gscene.num_objects - 1
     build_s = time.time() - t0
 
-    def camera_for(frame):
-        # frame 0 = the C2 camera of SURVEY 8d; the others swing around it by at most 1.8 degrees, so that every
-        # frame is the C2 view (same cost) but no two consecutive frames or ranks render the same rays
-        a = 0.001 * (frame % 32)
-        c = dict(scenes.C2_CAMERA)
-        vx, vy, vz = c["view"]
-        ca, sa = math.cos(a), math.sin(a)
-        c["view"] = (vx * ca - vy * sa, vx * sa + vy * ca, vz)
-        c["eye"] = tuple(-x for x in c["view"])
-        c["left"] = (-c["eye"][1], c["eye"][0], 0.0)
-        return rta.Camera(**c)
+    cams = [rta.Camera(**W.c2_orbit_camera(f)) for f in range(32)]
+    cam0 = cams[0]
+    Wd, Ht = cam0.width, cam0.height
+    npix = Wd * Ht
+    emulate = args.emulate_world if world == 1 else 0
+    tw = emulate or world                                   # ranks the frame is split over
+    tiles_mode = args.mode == "tiles" and tw > 1
+    S = args.streams or (4 if tw >= 4 else 2)
+    F = max(1, args.frames_per_step)
+    G = max(S, min(args.sub_batch, F))
+    while F % G:
+        G -= 1
+    stream0 = torch.cuda.current_stream()
+    streams = [stream0] + [torch.cuda.Stream() for _ in range(S - 1)]
+    shared_keep = [gscene.share(ctx) for _ in range(S - 1)]
+    handles = [raw_scene] + [sh.raw for sh in shared_keep]
+    comm_stream = torch.cuda.Stream() if tiles_mode else None
+    params_full = rta.Params(background=(200, 200, 200), frame_format=1)
+    params_f64 = rta.Params(background=(200, 200, 200))
 
-    cam0 = camera_for(0)
-    W, H = cam0.width, cam0.height
-    npix = W * H
-    rgb = [torch.zeros(npix * 3, dtype=torch.float64, device=dev) for _ in range(2)]
-    prim = torch.zeros(npix, dtype=torch.int32, device=dev)
-    params = rta.Params(background=(200, 200, 200))
-    stream = torch.cuda.current_stream()
-    sptr = C.c_void_p(stream.cuda_stream)
-    # frames in flight: frame k runs on stream k % S with its own scene handle (the handle owns the per-frame
-    # scratch), so the low-occupancy tail of one frame's kernels is filled by the next frame's waves
-    S = max(1, args.streams)
-    fl_streams = [stream] + [torch.cuda.Stream() for _ in range(S - 1)]
-    fl_scenes_keep = [gscene.share(ctx) for _ in range(S - 1)]
-    fl_scenes = [raw_scene] + [sh.raw for sh in fl_scenes_keep]
-    fl_rgb = [[torch.zeros(npix * 3, dtype=torch.float64, device=dev) for _ in range(2)] for _ in range(S)]
-    fl_prim = [prim] + [torch.zeros(npix, dtype=torch.int32, device=dev) for _ in range(S - 1)]
-    comm_stream = torch.cuda.Stream() if (world > 1 and args.mode == "samples") else None
+    total_st, per_rank = C.c_uint32(), C.c_uint32()
+    rta.check(rta.hip.rt_hip_tile_shard_info(cam0.raw, tw, C.byref(total_st), C.byref(per_rank)))
+    blk = per_rank.value * 8192 * 3                         # bytes of one rank's BGR8 shard of one frame
+    comm = None
+    comm_kind = "none"
+    if tiles_mode:
+        params_tile = rta.Params(background=(200, 200, 200), frame_format=1, tile_offset=rank, tile_stride=tw)
+        send = [torch.zeros(G * blk, dtype=torch.uint8, device=dev) for _ in range(2)]
+        recv = [torch.zeros(tw * G * blk, dtype=torch.uint8, device=dev) for _ in range(2)] if not emulate else None
+        frames = [torch.zeros((G, npix * 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        gather_done = [torch.cuda.Event(), torch.cuda.Event()]
+        if world > 1:
+            if args.comm == "abi" and not D.rehearsal:
+                comm = make_abi_comm(rta, ctx, D)
+            comm_kind = "rt_hip_comm_all_gather (RCCL)" if comm is not None else ("torch.distributed all_gather_into_tensor (%s)" % args.backend)
+    else:
+        frames = [torch.zeros((max(2 * S, 2), npix * 3), dtype=torch.uint8, device=dev)]
 
-    def render(step, buf):
-        frame = (step * world + rank) if args.mode == "frames" else 0
-        cam = cam0 if frame == 0 else camera_for(frame)
-        if args.mode == "samples":
-            params.seed = step * world + rank
-        k = step % S
-        rta.check(rta.hip.rt_hip_render_whitted_dev(fl_scenes[k], cam.raw, params, C.c_void_p(buf.data_ptr()),
-                                                    C.c_void_p(fl_prim[k].data_ptr()), C.c_void_p(fl_streams[k].cuda_stream)))
-        return cam
+    def gather(set_i):
+        """all-gather sub-batch `set_i` and put its G frames into raster order, on the comm stream"""
+        for st in streams:
+            comm_stream.wait_stream(st)
+        if emulate:
+            return
+        with torch.cuda.stream(comm_stream):
+            if comm is not None:
+                rta.check(rta.hip.rt_hip_comm_all_gather(comm, C.c_void_p(send[set_i].data_ptr()), C.c_void_p(recv[set_i].data_ptr()), G * blk,
+                                                         C.c_void_p(comm_stream.cuda_stream)))
+            elif D.rehearsal:                       # gloo: host tensors only
+                comm_stream.synchronize()
+                h_send = send[set_i].cpu(); h_recv = torch.empty(tw * G * blk, dtype=torch.uint8)
+                D.dist.all_gather_into_tensor(h_recv, h_send)
+                recv[set_i].copy_(h_recv)
+            else:
+                D.dist.all_gather_into_tensor(recv[set_i], send[set_i])
+            for g in range(G):
+                rta.check(rta.hip.rt_hip_tiles_to_frame_dev(cam0.raw, tw, C.c_void_p(recv[set_i].data_ptr() + g * blk), G * blk, 3,
+                                                            C.c_void_p(frames[set_i][g].data_ptr()), C.c_void_p(comm_stream.cuda_stream)))
+            gather_done[set_i].record(comm_stream)
 
     def one_step(step):
-        buf = fl_rgb[step % S][(step // S) & 1]
-        cam = render(step, buf)
-        if comm_stream is not None:
-            # radiance all-reduce of this step overlaps the next step's render
-            comm_stream.wait_stream(fl_streams[step % S])
-            with torch.cuda.stream(comm_stream):
-                if rehearsal:                      # gloo: the collective runs on a host copy (N ranks rehearsed on one GPU)
-                    host = buf.cpu(); dist.all_reduce(host); buf.copy_(host)
-                else:
-                    dist.all_reduce(buf)
-        return cam
+        for j in range(F):
+            f = step * F + j
+            k = f % S
+            if tiles_mode:
+                set_i, g = (f // G) & 1, f % G
+                if g < S:
+                    streams[k].wait_event(gather_done[set_i])      # the gather that last read this buffer set has finished
+                rta.check(rta.hip.rt_hip_render_whitted_dev(handles[k], cams[f % 32].raw, params_tile, C.c_void_p(send[set_i].data_ptr() + g * blk), None,
+                                                            C.c_void_p(streams[k].cuda_stream)))
+                if g == G - 1:
+                    gather(set_i)
+            else:
+                fr = (f * world + rank) if world > 1 else f        # replicas: every rank its own frames
+                rta.check(rta.hip.rt_hip_render_whitted_dev(handles[k], cams[fr % 32].raw, params_full, C.c_void_p(frames[0][f % frames[0].shape[0]].data_ptr()), None,
+                                                            C.c_void_p(streams[k].cuda_stream)))
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- statistics passes (outside the timed region): per-ray work of the traversal actually performed,
-    #      separately for the primary pass (same scene without its light) and the shadow pass (difference) ----
-    def stats_of(scene_raw):
-        pstat = rta.Params(background=(200, 200, 200), collect_stats=1)
-        ctx.stats(reset=True)
-        rta.check(rta.hip.rt_hip_render_whitted_dev(scene_raw, cam0.raw, pstat, C.c_void_p(rgb[0].data_ptr()), C.c_void_p(prim.data_ptr()), sptr))
-        torch.cuda.synchronize()
-        return ctx.stats(reset=True)
-
-    st_all = stats_of(raw_scene)
-    rays_pf, shadow_pf = C.c_uint64(0), C.c_uint64(0)
-    rta.check(rta.hip.rt_hip_last_ray_count(raw_scene, C.byref(rays_pf), C.byref(shadow_pf)))
-    rays_per_frame = rays_pf.value
-    dark, _ = scenes.build_heightfield(args.cells, gpu=True, oracle=False, leaf_refine=args.leaf_refine, light=False)
-    st_primary = stats_of(dark.device(ctx))
-    del dark
-    st_shadow = {k: st_all[k] - st_primary[k] for k in st_all}
+    # ---- rays per frame (the census of the kernels themselves) ----
+    if tiles_mode:
+        rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cam0.raw, params_tile, C.c_void_p(send[0].data_ptr()), None, None))
+    else:
+        rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cam0.raw, params_full, C.c_void_p(frames[0][0].data_ptr()), None, None))
+    torch.cuda.synchronize()
+    my_rays, my_shadow = last_rays(rta, raw_scene)
+    if tiles_mode:
+        rays_per_frame = D.reduce(my_rays, "sum") if not emulate else float(my_rays) * tw
+    else:
+        rays_per_frame = float(my_rays)
 
     for w in range(args.warmup):
         one_step(w)
-    barrier()
-    rta.check(rta.hip.rt_hip_set_profiling(raw_scene, 0 if args.no_profile else 1))
-    prof = rta.Profile()
-    rta.check(rta.hip.rt_hip_get_profile(raw_scene, C.byref(prof), 1))
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
+    D.barrier()
     t_start = time.perf_counter()
-    ev0.record(stream)
     for s in range(args.steps):
         one_step(s)
-    ev1.record(stream)
     if comm_stream is not None:
-        stream.wait_stream(comm_stream)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    ev_ms = ev0.elapsed_time(ev1)
-    rta.check(rta.hip.rt_hip_get_profile(raw_scene, C.byref(prof), 1))
-    rta.check(rta.hip.rt_hip_set_profiling(raw_scene, 0))
-
-    # for reference, outside the timed region: the same frames strictly one after the other
-    t1 = time.perf_counter()
-    n_one = min(args.steps, 10)
-    for s_ in range(n_one):
-        cam_ = camera_for(s_ * world + rank) if args.mode == "frames" else cam0      # held: .raw points into it
-        rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cam_.raw, params,
-                                                    C.c_void_p(fl_rgb[0][0].data_ptr()), C.c_void_p(prim.data_ptr()), sptr))
-    torch.cuda.synchronize()
-    ms_one_in_flight = (time.perf_counter() - t1) * 1e3 / n_one
-
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        rr = torch.tensor([float(rays_per_frame)], dtype=torch.float64, device=cdev)
-        dist.all_reduce(rr)
-        total_rays_per_step = float(rr.item())
-    else:
-        total_rays_per_step = float(rays_per_frame)
-
+        stream0.wait_stream(comm_stream)
+    D.barrier()
+    elapsed = D.reduce(time.perf_counter() - t_start, "max")
+    frames_total = F * args.steps * (world if (world > 1 and not tiles_mode) else 1)
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
+        return None
     ms_per_step = elapsed * 1e3 / args.steps
-    value = total_rays_per_step * args.steps / elapsed / 1e6
-
-    # ---- roofline of the dominant kernel ----
-    kms = {rta.KERNEL_NAMES[i]: (prof.ms[i], prof.launches[i]) for i in range(12) if prof.launches[i]}
-    if not kms:
-        kms = {"k_shadow": (float("nan"), 1)}
-    dom = max(kms, key=lambda k: kms[k][0])
-    dom_ms = kms[dom][0] / kms[dom][1]
-    st = st_shadow if dom == "k_shadow" else st_primary if dom == "k_primary" else st_all
-    nrays = max(1, st["rays"])
-    nodes_per_ray = st["node_visits"] / nrays
-    prims_per_ray = st["prim_tests"] / nrays
-    exact_per_ray = st["exact_tests"] / nrays
-    # Algorithmic bytes of THIS traversal (DESIGN.md "Roofline"): a wave of 64 rays walks the tree as a packet, so
-    # a box test's 64 B (half a 128-B child pair, or a leaf header) and a cull record's 128 B are moved once per
-    # WAVE that needs them; rays in (48 B), hits out (32 B) and the 96-B exact triangles of the confirmation
-    # are per ray.  The per-lane figure (what 64 independent rays would fetch) is reported beside it.
-    wave_boxes_per_ray = st["wave_node_visits"] / nrays
-    wave_recs_per_ray = st["wave_prim_tests"] / nrays
-    # k_frame_direct generates its rays and keeps the hits in registers: its only per-ray traffic is the frame
-    # (24 B colour + 4 B id per pixel = per 2 rays)
-    io_bytes = 14 if dom == "k_frame_direct" else 48 + 32
-    bytes_per_ray = io_bytes + 64 * wave_boxes_per_ray + 128 * wave_recs_per_ray + 96 * exact_per_ray
-    lane_bytes_per_ray = io_bytes + 64 * nodes_per_ray + 128 * prims_per_ray + 96 * exact_per_ray
-    flops_per_ray = 40 * nodes_per_ray + 45 * prims_per_ray + 150 * exact_per_ray
-    rays_dom = (rays_per_frame - shadow_pf.value) if dom == "k_primary" else shadow_pf.value if dom == "k_shadow" else rays_per_frame
-    ach_gbs = bytes_per_ray * rays_dom / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    tf = flops_per_ray * rays_dom / (dom_ms * 1e-3) / 1e12
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel_ms": round(dom_ms, 4), "rays_per_launch": int(rays_dom),
-                "bytes_per_ray": round(bytes_per_ray, 1), "lane_bytes_per_ray": round(lane_bytes_per_ray, 1),
-                "box_tests_per_ray": round(nodes_per_ray, 2), "cull_records_per_ray": round(prims_per_ray, 2),
-                "exact_tests_per_ray": round(exact_per_ray, 3),
-                "wave_box_fetches_per_ray": round(wave_boxes_per_ray, 3), "wave_record_fetches_per_ray": round(wave_recs_per_ray, 3),
-                "note": "scene (0.3 GB) is L2/Infinity-Cache resident: the walk is bound by FP64 VALU issue + LDS/scalar latency, not HBM",
-                "valu_fp64": {"achieved_tflops": round(tf, 2), "peak_tflops": FP64_VALU_PEAK_TF, "frac": round(tf / FP64_VALU_PEAK_TF, 4)},
-                "all_kernels_ms": {k: round(v[0] / v[1], 4) for k, v in kms.items()}}
-
-    # ---- CPU baseline: the oracle (reference semantics, exhaustive BSP walk) on the host cores ----
-    cpu = None
-    if not args.no_cpu_baseline:
-        import oracle_bind as ob
-        _, oscene = scenes.build_heightfield(args.cells, gpu=False, oracle=True)
-        ocam = scenes.oracle_camera(scenes.C2_CAMERA)
-        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-        rows = args.cpu_rows or 8
-        # calibrate on a few rows in the middle of the frame, then size the sample for ~15 s
-        first = (H // 2) * W
-        t1 = time.perf_counter()
-        _, _, cnt = oscene.render_whitted(ocam, background=(200, 200, 200), first=first, count=rows * W, threads=threads, counters=True)
-        dt = time.perf_counter() - t1
-        if not args.cpu_rows:
-            rows = int(max(8, min(H, rows * 15.0 / max(dt, 1e-3))))
-            first = ((H - rows) // 2) * W
-            t1 = time.perf_counter()
-            _, _, cnt = oscene.render_whitted(ocam, background=(200, 200, 200), first=first, count=rows * W, threads=threads, counters=True)
-            dt = time.perf_counter() - t1
-        cpu_rays = int(cnt[0])
-        cpu = {"value": round(cpu_rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-               "sample": "%d centre rows of the same 1920x1080 frame (%d rays, %.1f s), oracle/rt_oracle.c OpenMP" % (rows, cpu_rays, dt),
-               "node_visits_per_ray": round(float(cnt[1]) / max(1, cpu_rays), 1), "prim_tests_per_ray": round(float(cnt[2]) / max(1, cpu_rays), 1)}
+    value = rays_per_frame * frames_total / elapsed / 1e6
+    scaling = "strong" if (tiles_mode or world == 1) else "weak"
 
     out = {"metric": "Mrays/sec (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "C2: synthetic %d-triangle heightfield + ground plane, primary+shadow ray casting %dx%d, 1 frame per GPU per step"
-                                  % (n_tris, W, H), "triangles": n_tris, "resolution": [W, H], "rays_per_frame": int(rays_per_frame),
-                      "shadow_rays_per_frame": int(shadow_pf.value), "parallelism": "%s x%d" % (args.mode, world), "frames_in_flight": S, "ms_per_frame_one_in_flight": round(ms_one_in_flight, 4),
-                      "leaf_refine": "library default (own hierarchy, leaves < 24)" if args.leaf_refine is None else args.leaf_refine, "scene_build_s": round(build_s, 2), "event_ms_per_step": round(ev_ms / args.steps, 4)},
-           "roofline": roofline, "cpu_baseline": cpu}
-    print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+           "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "C2: synthetic %d-triangle heightfield + ground plane, primary+shadow ray casting %dx%d; a step = %d frames (camera swinging <= 1.8 deg around "
+                                  "the C2 view), each to the Vec3b picture of Camera.h:69" % (n_tris, Wd, Ht, F),
+                      "triangles": n_tris, "resolution": [Wd, Ht], "frames_per_step": F, "rays_per_frame": int(rays_per_frame),
+                      "ms_per_frame": round(ms_per_step / F, 4), "frames_in_flight": S,
+                      "parallelism": ("one frame split over %d ranks by interleaved 128x64 super-tiles, %d-frame all-gather: %s" % (tw, G, comm_kind)) if tiles_mode
+                                     else ("replicas x%d (no collective)" % world if world > 1 else "1 GPU"),
+                      "leaf_refine": "library default (own hierarchy, leaves < 24)" if args.leaf_refine is None else args.leaf_refine,
+                      "scene_build_s": round(build_s, 2)}}
+    if emulate:
+        out["config"]["emulated"] = "rank 0's share of a %d-rank run on one GPU, no collective: value = this rank's rate x %d (a projection, not a result)" % (tw, tw)
+    if world > 1 or emulate:
+        return out                          # the roofline / CPU legs belong to the one-GPU line
+
+    # =========================== one GPU: roofline, secondary figures, CPU baseline ===========================
+    # ---- kernel time with ONE frame in flight, HIP events on the kernel's own stream (rt_hip_set_profiling) ----
+    rgb64 = torch.zeros(npix * 3, dtype=torch.float64, device=dev)
+    prim = torch.zeros(npix, dtype=torch.int32, device=dev)
+    sptr = C.c_void_p(stream0.cuda_stream)
+    rta.check(rta.hip.rt_hip_set_profiling(raw_scene, 1))
+    prof = rta.Profile()
+    rta.check(rta.hip.rt_hip_get_profile(raw_scene, C.byref(prof), 1))
+    n_one = 20
+    t1 = time.perf_counter()
+    for s_ in range(n_one):
+        rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cams[s_ % 32].raw, params_full, C.c_void_p(frames[0][0].data_ptr()), None, sptr))
+    torch.cuda.synchronize()
+    ms_one_in_flight = (time.perf_counter() - t1) * 1e3 / n_one
+    rta.check(rta.hip.rt_hip_get_profile(raw_scene, C.byref(prof), 1))
+    rta.check(rta.hip.rt_hip_set_profiling(raw_scene, 0))
+    kms = {rta.KERNEL_NAMES[i]: prof.ms[i] / prof.launches[i] for i in range(12) if prof.launches[i]}
+    dom = max(kms, key=lambda k: kms[k])
+    dom_ms = kms[dom]
+
+    # ---- per-ray work of the traversal actually performed (statistics build of the same kernel) ----
+    pstat = rta.Params(background=(200, 200, 200), collect_stats=1)
+    ctx.stats(reset=True)
+    rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cam0.raw, pstat, C.c_void_p(rgb64.data_ptr()), C.c_void_p(prim.data_ptr()), sptr))
+    torch.cuda.synchronize()
+    st = ctx.stats(reset=True)
+    rays_dom, shadow_rays = last_rays(rta, raw_scene)
+    nrays = max(1, st["rays"])
+    nodes_per_ray, prims_per_ray, exact_per_ray = st["node_visits"] / nrays, st["prim_tests"] / nrays, st["exact_tests"] / nrays
+    wave_boxes_per_ray, wave_recs_per_ray = st["wave_node_visits"] / nrays, st["wave_prim_tests"] / nrays
+    # Algorithmic bytes, two definitions.  PACKET: a wave of 64 rays walks the tree together, so a
+    # box test's 64 B (half a 128-B child pair, or a leaf header) and a cull record's 128 B move once per WAVE that needs
+    # them; the 96-B exact triangle of a confirmation is per ray; the frame is 3 B per pixel = per two rays.  LANE: what 64
+    # independent rays would fetch (SURVEY 8d's per-ray formula on this traversal's counts) -- served from LDS / SGPR
+    # broadcasts, not from HBM.
+    io_bytes = 1.5
+    bytes_per_ray = io_bytes + 64 * wave_boxes_per_ray + 128 * wave_recs_per_ray + 96 * exact_per_ray
+    lane_bytes_per_ray = io_bytes + 64 * nodes_per_ray + 128 * prims_per_ray + 96 * exact_per_ray
+    flops_per_ray = 40 * nodes_per_ray + 45 * prims_per_ray + 150 * exact_per_ray
+    ach_gbs = bytes_per_ray * rays_dom / (dom_ms * 1e-3) / 1e9
+    tf = flops_per_ray * rays_dom / (dom_ms * 1e-3) / 1e12
+    pmc = read_traffic(dom)
+    valu_insts = pmc.get("SQ_INSTS_VALU")                  # wave-level VALU instructions per launch (rocprofv3 --pmc pass)
+    cycles = pmc.get("kernel_cycles")                      # GRBM_GUI_ACTIVE per launch / 8 XCDs
+    if valu_insts:
+        ach_issue = valu_insts / (dom_ms * 1e-3) / 1e9     # G wave-instructions/s against the live kernel time
+        frac_issue = ach_issue / VALU_ISSUE_PEAK_G
+        frac_issue_measured_clock = (valu_insts * 4.0 / N_SIMD / cycles) if cycles else None
+    else:
+        ach_issue = frac_issue = frac_issue_measured_clock = None
+    roofline = {"bound": "valu_issue", "kernel": dom, "achieved": round(ach_issue, 1) if ach_issue else None, "peak": VALU_ISSUE_PEAK_G,
+                "unit": "G wave-instructions/s", "frac": round(frac_issue, 4) if frac_issue else None,
+                "frac_at_measured_clock": round(frac_issue_measured_clock, 4) if frac_issue_measured_clock else None,
+                "traffic": pmc.get("hbm_bytes_per_launch"),
+                "kernel_ms": round(dom_ms, 4), "kernel_ms_source": "HIP events on the kernel's stream, one frame in flight, %d launches" % n_one,
+                "rays_per_launch": int(rays_dom), "valu_wave_insts_per_launch": valu_insts,
+                "valu_lane_insts_per_ray": round(valu_insts * 64.0 / rays_dom, 1) if valu_insts else None,
+                "note": "the walk is bound by VALU issue (FP64 cull / slab arithmetic + the integer work around it), not by HBM: the scene (0.2 GB) is L2 / "
+                        "Infinity-Cache resident.  peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; SQ_INSTS_VALU from profiles/r02_traffic.json",
+                "hbm": {"achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4),
+                        "bytes_per_ray": round(bytes_per_ray, 1), "bytes_definition": "packet: node / record bytes once per wave that needs them",
+                        "lane_bytes_per_ray": round(lane_bytes_per_ray, 1), "lane_bytes_definition": "what 64 independent rays would fetch (served by LDS / SGPR broadcasts)"},
+                "valu_fp64": {"achieved_tflops": round(tf, 2), "peak_tflops": FP64_VALU_PEAK_TF, "frac": round(tf / FP64_VALU_PEAK_TF, 4), "flops_per_ray": round(flops_per_ray, 1)},
+                "box_tests_per_ray": round(nodes_per_ray, 2), "cull_records_per_ray": round(prims_per_ray, 2), "exact_tests_per_ray": round(exact_per_ray, 3),
+                "wave_box_fetches_per_ray": round(wave_boxes_per_ray, 3), "wave_record_fetches_per_ray": round(wave_recs_per_ray, 3),
+                "all_kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
+    out["roofline"] = roofline
+    out["config"]["ms_per_frame_one_in_flight"] = round(ms_one_in_flight, 4)
+    out["config"]["shadow_rays_per_frame"] = int(shadow_rays)
+
+    def timed_frames(handle_list, params, bufs, n, ids=None):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for f in range(n):
+            k = f % len(handle_list)
+            rta.check(rta.hip.rt_hip_render_whitted_dev(handle_list[k], cams[f % 32].raw, params, C.c_void_p(bufs[k].data_ptr()),
+                                                        C.c_void_p(ids[k].data_ptr()) if ids else None, C.c_void_p(streams[k].cuda_stream)))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
+    if not args.no_extras:
+        # ---- secondary: the f64 R,G,B + prim-id frame of round 1's line; the reference's own BSP tree on the device ----
+        b64 = [rgb64] + [torch.zeros(npix * 3, dtype=torch.float64, device=dev) for _ in range(S - 1)]
+        bid = [prim] + [torch.zeros(npix, dtype=torch.int32, device=dev) for _ in range(S - 1)]
+        dt = timed_frames(handles, params_f64, b64, 40, bid)
+        out["config"]["f64_rgb_plus_ids_frame_mrays"] = round(rays_per_frame / dt / 1e6, 1)
+        del b64, bid
+        t_r = time.time()
+        ref_scene = W.build_heightfield(W.product_stage, args.cells, leaf_refine=0xFFFFFFFF).sides[0][0]      # RT_HIP_LEAF_REFINE_NONE
+        ref_raw = ref_scene.device(ctx)
+        ref_share = [ref_scene.share(ctx) for _ in range(S - 1)]
+        bufs8 = [frames[0][k % frames[0].shape[0]] for k in range(S)]
+        timed_frames([ref_raw] + [r.raw for r in ref_share], params_full, bufs8, 4)
+        dt = timed_frames([ref_raw] + [r.raw for r in ref_share], params_full, bufs8, 24)
+        out["config"]["reference_tree_mrays"] = round(rays_per_frame / dt / 1e6, 1)
+        out["config"]["reference_tree_note"] = "RT_HIP_LEAF_REFINE_NONE: the device walks BSPTree.h's own tree (leaves < 100 objects, 1.85 M references)"
+        del ref_share, ref_scene
+        # the allocation-free entry point on the same frame
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for f in range(20):
+            rta.check(rta.hip.rt_hip_render_whitted_noalloc(raw_scene, cams[f % 32].raw, params_full, C.c_void_p(frames[0][0].data_ptr()), None, sptr))
+        torch.cuda.synchronize()
+        out["config"]["noalloc_entry_point_ms_per_frame"] = round((time.perf_counter() - t) * 1e3 / 20, 4)
+
+    # ---- CPU baseline + whole-frame parity: the oracle (reference semantics, exhaustive BSP walk) on the host cores ----
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import numpy as np
+        import scenes
+        import parity_util
+        _, oscene = scenes.build_heightfield(args.cells, gpu=False, oracle=True)
+        ocam = scenes.oracle_camera(W.C2_CAMERA)
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        t1 = time.perf_counter()
+        ref_rgb, ref_ids, cnt = oscene.render_whitted(ocam, background=(200, 200, 200), threads=threads, counters=True)
+        dt = time.perf_counter() - t1
+        cpu_rays = int(cnt[0])
+        out["cpu_baseline"] = {"value": round(cpu_rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                               "sample": "the whole 1920x1080 C2 frame once (%d rays, %.1f s), oracle/rt_oracle.c with OpenMP" % (cpu_rays, dt),
+                               "node_visits_per_ray": round(float(cnt[1]) / max(1, cpu_rays), 1), "prim_tests_per_ray": round(float(cnt[2]) / max(1, cpu_rays), 1)}
+        rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cam0.raw, params_f64, C.c_void_p(rgb64.data_ptr()), C.c_void_p(prim.data_ptr()), sptr))
+        torch.cuda.synchronize()
+        g_rgb, g_ids = rgb64.cpu().numpy().reshape(-1, 3), prim.cpu().numpy()
+        rays_np, _, _ = oscene.camera_rays(ocam)
+
+        def t_of(idx):
+            hits = gscene.first_inter_pt(ctx, rays_np[idx])
+            _, pts = oscene.trace_closest(rays_np[idx], use_bsp=True)
+            return hits["t"], np.linalg.norm(pts - rays_np[idx, :3], axis=1)
+        out["parity"] = parity_util.frame_parity(g_rgb, g_ids, ref_rgb, ref_ids, t_of, two_class_ids=lambda i: np.where(i < 0, -1, np.minimum(i, 1)))
+        out["parity"]["what"] = "all primary hit ids, shadow bits and radiance of the C2 frame, HIP vs oracle; bar: tie_fraction <= 1e-4, max_dt < 1e-6, colour < 1e-3"
+        del oscene
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def other_config(name, args, D, torch, rta, W, ctx, short):
+    """C3 / C4 / C5 on their stated geometry at 1080p.  `short`: a cut-down run for config.other_configs of the default
+    line.  N > 1: C3 splits the samples (all-reduce of the un-clamped sums), C5 the photons (all-reduce of the per-hit-
+    point statistics), C4 the rows (all-gather)."""
+    from ray_tracing_amd import parallel
+    rank, world, dev = D.rank, D.world, D.dev
+    res = {}
+    if name == "C3":
+        g = W.build_icosahedron(W.product_stage, material="plastic", light="area10").sides[0][0]
+        cam = rta.Camera(**W.C3_CAMERA)
+        n = cam.width * cam.height
+        spp_total = 1024
+        spp_run = args.spp or (2 if short else 8)
+        rgb = torch.zeros(n * 3, dtype=torch.float64, device=dev)
+        s0, cnt = parallel.sample_shard(spp_run, rank, world)
+        p = rta.Params(background=(200, 200, 200), spp=spp_total, lens_radius=0.1, sample_first=s0, sample_count=max(cnt, 1), seed=1)
+        raw = g.device(ctx)
+
+        def step():
+            if cnt:
+                rta.check(rta.hip.rt_hip_render_focusing_dev(raw, cam.raw, p, C.c_void_p(rgb.data_ptr()), None))
+            if world > 1:
+                if D.rehearsal:
+                    h = rgb.cpu(); D.dist.all_reduce(h); rgb.copy_(h)
+                else:
+                    D.dist.all_reduce(rgb)
+        step(); torch.cuda.synchronize()
+        rays = D.reduce(last_rays(rta, raw)[0] if cnt else 0, "sum")
+        reps = 1 if short else max(1, args.steps)
+        D.barrier(); t = time.perf_counter()
+        for _ in range(reps):
+            step()
+        D.barrier()
+        dt = D.reduce((time.perf_counter() - t) / reps, "max")
+        res = {"workload": "C3: Layout3_Icosahedron, depth of field (Camera.h:171-199) %dx%d, 10x10 area light (100 shadow rays per lens sample), lens radius 0.1" % (cam.width, cam.height),
+               "samples_per_pixel_timed": spp_run, "rays": int(rays), "s_per_step": round(dt, 5), "Mrays_per_s": round(rays / dt / 1e6, 1),
+               "s_per_frame_at_1024spp": round(dt / spp_run * spp_total, 2), "extrapolated": spp_run != spp_total,
+               "parallelism": "sample split + all-reduce(sum) of the f64 frame" if world > 1 else "1 GPU"}
+        kernel = "k_shadow"
+    elif name == "C4":
+        g = W.build_paper(W.product_stage).sides[0][0]
+        assert g.num_objects == 11578, g.num_objects          # plane + patch + WallLight.obj's 11,576 triangles
+        cam = rta.Camera(**W.C4_CAMERA)
+        assert (cam.width, cam.height) == (1920, 1080)
+        n = cam.width * cam.height
+        spp_total = 256
+        spp_run = args.spp or (4 if short else 16)
+        aa = rta.AaParams(oversample_times=spp_run, depth_grad_threshold=-1.0)       # every pixel re-sampled: the fixed-spp jittered render
+        first, count = parallel.row_shard(cam.height, cam.width, rank, world)
+        p = rta.Params(background=(30, 30, 30), seed=1, pixel_first=first, pixel_count=count)
+        rgb = torch.zeros(max(count, 1) * 3, dtype=torch.float64, device=dev)
+        raw = g.device(ctx)
+
+        def step():
+            if count:
+                rta.check(rta.hip.rt_hip_render_antialiasing_dev(raw, cam.raw, p, aa, C.c_void_p(rgb.data_ptr()), None, None))
+            if world > 1 and not D.rehearsal:
+                parallel.gather_rows(rgb.view(-1, 3)[:count], cam.height, cam.width, 3)
+        step(); torch.cuda.synchronize()
+        rays = D.reduce(last_rays(rta, raw)[0] if count else 0, "sum")
+        reps = 1 if short else max(1, min(args.steps, 5))
+        D.barrier(); t = time.perf_counter()
+        for _ in range(reps):
+            step()
+        D.barrier()
+        dt = D.reduce((time.perf_counter() - t) / reps, "max")
+        res = {"workload": "C4: Layout2_WallAndPaper (Bezier patch + WallLight.obj, %d objects) %dx%d depth 2, pixel-jittered (r0 0.007), every pixel re-sampled" % (g.num_objects, cam.width, cam.height),
+               "samples_per_pixel_timed": spp_run, "rays": int(rays), "s_per_step": round(dt, 5), "Mrays_per_s": round(rays / dt / 1e6, 1),
+               "s_per_frame_at_256spp": round(dt / spp_run * spp_total, 2), "extrapolated": spp_run != spp_total,
+               "parallelism": "row split + all-gather" if world > 1 else "1 GPU"}
+        kernel = "k_trace_nodes"
+    else:
+        g = W.build_wine(W.product_stage, cups="layout", light="area5").sides[0][0]
+        assert g.num_objects == 24
+        cam = rta.Camera(**W.C5_CAMERA)
+        photon_num = args.photons or (20000 if short else 100000)                   # x 25 light samples per pass (full config: 400000 -> 10 M)
+        t = time.perf_counter()
+        pm = rta.PhotonMap(ctx, g, cam, photon_num=photon_num, times=64, background=(10, 10, 10), seed=1)
+        torch.cuda.synchronize()
+        t_eye = time.perf_counter() - t
+        eye_rays = last_rays(rta, g.device(ctx))[0]
+        info = pm.info()
+        passes = 1 if short else max(1, min(args.steps, 4))
+        D.barrier(); t = time.perf_counter()
+        for k in range(passes):
+            if world > 1 and not D.rehearsal:
+                parallel.ppm_pass_sharded(pm, k)
+            else:
+                pm.run_pass(k)
+        D.barrier()
+        dt = D.reduce((time.perf_counter() - t) / passes, "max")
+        i2 = pm.info()
+        segs = D.reduce(i2["photon_segments"], "sum")
+        res = {"workload": "C5: Layout5_Wine (three cups, uRange 0.7/0.5/0.8, 24 objects, no tree) %dx%d depth 8, 5x5 area light, progressive photon mapping" % (cam.width, cam.height),
+               "eye_pass_s": round(t_eye, 3), "eye_pass_rays": int(eye_rays), "hit_points": info["hitpoints"], "photons_per_pass_timed": info["photons_per_pass"],
+               "passes_timed": passes, "s_per_step": round(dt, 4), "photon_segments_per_pass": int(segs / passes), "rays": int(segs / passes),
+               "Mrays_per_s": round(segs / passes / dt / 1e6, 2), "s_per_pass_at_10M_photons": round(dt * 1e7 / info["photons_per_pass"], 3),
+               "extrapolated": info["photons_per_pass"] != 10000000, "parallelism": "photon split + all-reduce of (M, tau) per hit point" if world > 1 else "1 GPU"}
+        kernel = "k_ppm_trace"
+    pmc = read_traffic(kernel + ":" + name) or read_traffic(kernel)
+    if pmc.get("SQ_INSTS_VALU") and pmc.get("kernel_cycles"):
+        res["dominant_kernel"] = kernel
+        res["valu_issue_frac"] = round(pmc["SQ_INSTS_VALU"] * 4.0 / N_SIMD / pmc["kernel_cycles"], 4)
+    return res
+
+
+def cpu_sample(name, W, rows=2):
+    """the oracle on a bounded sample of C3 / C4 / C5 (a few seconds): a couple of image rows of the same frame"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import scenes
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    if name == "C3":
+        _, o = scenes.build_icosahedron(material="plastic", light="area10", gpu=False)
+        cam = scenes.oracle_camera(W.C3_CAMERA)
+        w = 1920
+        t = time.perf_counter()
+        o.render_focusing(cam, 0.1, 1, background=(200, 200, 200), seed=1, first=540 * w, count=rows * w, threads=threads)
+        dt = time.perf_counter() - t
+        rays = rows * w * 101
+        what = "%d centre rows x 1 lens sample of the C3 frame (camera ray + 100 shadow rays each)" % rows
+    elif name == "C4":
+        _, o = scenes.build_paper(gpu=False)
+        cam = scenes.oracle_camera(W.C4_CAMERA)
+        w = 1920
+        t = time.perf_counter()
+        _, _, cnt = o.render_whitted(cam, background=(30, 30, 30), first=540 * w, count=rows * w, threads=threads, counters=True)
+        dt = time.perf_counter() - t
+        rays = int(cnt[0])
+        what = "%d centre rows x 1 sample of the C4 frame, depth 2" % rows
+    else:
+        _, o = scenes.build_wine(gpu=False, cups="layout", light="area5")
+        cam = scenes.oracle_camera(W.C5_CAMERA)
+        w = 1920
+        t = time.perf_counter()
+        _, _, cnt = o.render_whitted(cam, background=(10, 10, 10), first=540 * w, count=w // 4, threads=threads, counters=True)
+        dt = time.perf_counter() - t
+        rays = int(cnt[0])
+        what = "a quarter of the centre row of the C5 eye pass (depth 8, 25 shadow rays per hit), Whitted part only"
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": "%s: %d rays, %.1f s, oracle/rt_oracle.c with OpenMP" % (what, rays, dt)}
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import torch
+    import ray_tracing_amd as rta
+    from ray_tracing_amd import workloads as W
+
+    D = Dist(args, torch)
+    if D.world != args.gpus:
+        args.gpus = D.world
+    if args.config == "C2":
+        out = bench_c2(args, D, torch, rta, W)
+        if out is not None and D.world == 1 and not args.emulate_world and not args.no_extras:
+            ctx = rta.Context(D.local_rank)
+            others = {}
+            for name in ("C3", "C4", "C5"):
+                try:
+                    others[name] = other_config(name, args, D, torch, rta, W, ctx, short=True)
+                    if not args.no_cpu_baseline:
+                        others[name]["cpu_baseline"] = cpu_sample(name, W, rows=48 if name == "C3" else 1)
+                except Exception as e:          # a secondary figure must not cost the headline line
+                    others[name] = {"error": repr(e)}
+            out["config"]["other_configs"] = others
+    else:
+        ctx = rta.Context(D.local_rank)
+        res = other_config(args.config, args, D, torch, rta, W, ctx, short=False)
+        out = None
+        if D.rank == 0:
+            out = {"metric": "Mrays/sec (primary+secondary)", "value": res["Mrays_per_s"], "unit": "Mrays/s", "n_gpus": D.world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": round(res["s_per_step"] * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                   "dtype": "f64", "data": "synthetic", "config": res}
+            pmc_k = res.get("dominant_kernel")
+            out["roofline"] = {"bound": "valu_issue", "kernel": pmc_k, "frac": res.get("valu_issue_frac"), "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instructions/s",
+                               "achieved": round(res["valu_issue_frac"] * VALU_ISSUE_PEAK_G, 1) if res.get("valu_issue_frac") else None, "traffic": None,
+                               "note": "from the rocprofv3 --pmc passes of this config kept in profiles/r02_traffic.json (SQ_INSTS_VALU x 4 / 1024 SIMDs / kernel cycles)"}
+            if not args.no_cpu_baseline and D.world == 1:
+                out["cpu_baseline"] = cpu_sample(args.config, W, rows=2)
+    if D.rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+    D.finish()
 
 
 if __name__ == "__main__":

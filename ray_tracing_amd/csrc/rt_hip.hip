@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -51,10 +52,22 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+// Contexts and scenes are reference counted: a scene keeps its context, a photon map / god ray / communicator keeps what it was
+// made from, so that handles may be destroyed in any order (a destroy call drops the caller's reference; the memory goes
+// with the last one).
 struct rt_hip_ctx {
   int device = 0;
   Stats *d_stats = nullptr;      // accumulated counters
+  std::atomic<int> refs{1};
 };
+static void ctx_retain(rt_hip_ctx *c) { if (c) c->refs.fetch_add(1); }
+static void ctx_release(rt_hip_ctx *c)
+{
+  if (!c || c->refs.fetch_sub(1) != 1) return;
+  if (hipSetDevice(c->device) != hipSuccess) (void)hipGetLastError();      // never leave a sticky error behind
+  if (c->d_stats) (void)hipFree(c->d_stats);
+  delete c;
+}
 
 // one node of the ray tree of a pixel sample (level arrays of the wavefront Whitted integrator)
 struct alignas(16) PathNode {
@@ -69,6 +82,7 @@ static_assert(sizeof(PathNode) == 128, "PathNode layout");
 
 struct rt_hip_godray;
 struct rt_hip_scene {
+  std::atomic<int> refs{1};        // the caller's handle + one per photon map / god ray made from it
   rt_hip_ctx *ctx = nullptr;
   rt_hip_godray *god = nullptr;    // set for the duration of rt_hip_render_godray: run_levels adds the light-shaft radiance
   DevScene dev{};
@@ -76,7 +90,7 @@ struct rt_hip_scene {
   struct Geometry { std::vector<void *> allocs; ~Geometry() { for (void *p : allocs) (void)hipFree(p); } };
   std::shared_ptr<Geometry> geo = std::make_shared<Geometry>();
   // render workspace (grow-only, reused between calls)
-  static constexpr int kMaxLevels = 16;
+  static constexpr int kMaxLevels = 12;   // = the ray-tree path bits of rng_counter (rt_math.hpp): level L numbers its rays below 2^(L+1); the reference's layouts use depth <= 8
   DevBuf levels[kMaxLevels];
   DevBuf order;                   // heavy-first wave order lists + flags
   DevBuf lum;                     // per node, per light luminosity (shadow pass -> shade pass)
@@ -1090,10 +1104,7 @@ extern "C" int rt_hip_context_create(int device_id, rt_hip_ctx **out)
 
 extern "C" int rt_hip_context_destroy(rt_hip_ctx *ctx)
 {
-  if (!ctx) return RT_HIP_OK;
-  (void)hipSetDevice(ctx->device);
-  if (ctx->d_stats) (void)hipFree(ctx->d_stats);
-  delete ctx;
+  ctx_release(ctx);
   return RT_HIP_OK;
 }
 
@@ -1110,15 +1121,17 @@ extern "C" int rt_hip_get_stats(rt_hip_ctx *ctx, rt_hip_stats *out, int reset)
   return RT_HIP_OK;
 }
 
+static void scene_retain(rt_hip_scene *s) { if (s) s->refs.fetch_add(1); }
 extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
 {
-  if (!s) return RT_HIP_OK;
-  if (s->ctx) (void)hipSetDevice(s->ctx->device);
+  if (!s || s->refs.fetch_sub(1) != 1) return RT_HIP_OK;      // a photon map or god ray still renders with it
+  if (s->ctx && hipSetDevice(s->ctx->device) != hipSuccess) (void)hipGetLastError();
   s->geo.reset();
   for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &b : s->levels) b.release();
   for (auto &b : s->uv) b.release();
   s->counter.release(); s->staging.release(); s->lum.release(); s->order.release(); s->aa_maps.release(); s->aa_edges.release();
+  ctx_release(s->ctx);
   delete s;
   return RT_HIP_OK;
 }
@@ -1181,7 +1194,7 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
 
   HIP_TRY(hipSetDevice(ctx->device));
   rt_hip_scene *s = new rt_hip_scene();
-  s->ctx = ctx;
+  s->ctx = ctx; ctx_retain(ctx);
   Builder B; B.d = d;
   // rt_hip.h: DEFAULT = the library's own hierarchy with its tuned leaf size; NONE = the reference's tree as described;
   // n = the reference's tree with its leaves split down to n objects; RT_HIP_LEAF_REFINE_OWN | n = own hierarchy, leaf size n
@@ -1309,7 +1322,7 @@ extern "C" int rt_hip_scene_share(rt_hip_scene *src, rt_hip_scene **out)
 {
   if (!src || !out) return fail(RT_HIP_EINVAL, "NULL argument");
   rt_hip_scene *s = new rt_hip_scene();
-  s->ctx = src->ctx; s->dev = src->dev; s->geo = src->geo;
+  s->ctx = src->ctx; ctx_retain(s->ctx); s->dev = src->dev; s->geo = src->geo;
   s->n_nodes = src->n_nodes; s->n_leaves = src->n_leaves; s->n_cull = src->n_cull; s->max_depth = src->max_depth;
   s->one_sample = src->one_sample;
   *out = s;
@@ -1470,7 +1483,7 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
   unsigned int n_level[rt_hip_scene::kMaxLevels] = {0};
   n_level[0] = (unsigned int)n0;
   int depth = A.cam.depth < 1 ? 1 : A.cam.depth;
-  if (depth > rt_hip_scene::kMaxLevels) return fail(RT_HIP_EUNSUPPORTED, "camera depth > 16");
+  if (depth > rt_hip_scene::kMaxLevels) return fail(RT_HIP_EUNSUPPORTED, "camera depth > 12: the sampler keys 12 bits of ray-tree path (rng_counter), deeper rays would share random streams");
   int last = 0;
   for (int lv = 0; lv < depth; lv++) {
     const unsigned int n = n_level[lv];
@@ -1547,7 +1560,9 @@ static int order_waves(rt_hip_scene *s, const RenderArgs &A, uint64_t n_waves, v
   HIP_TRY(hipGetLastError());
   return RT_HIP_OK;
 }
-// a depth-1 frame in one launch (k_frame_direct); lum: n0 * n_lights doubles, not read when the scene has one light of one sample
+// does the depth-1 frame take the loop-free kernel (one light of one sample: the luminosity stays in a register, no lum array)?
+static inline bool frame_direct_one(const rt_hip_scene *s, bool stats) { return !stats && !s->dev.has_param && s->one_sample; }
+// a depth-1 frame in one launch (k_frame_direct); lum: n0 * n_lights doubles, needed unless frame_direct_one()
 static int launch_frame_direct(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStream_t st, uint64_t n_waves, const unsigned int *order0,
                                double *lum, RenderCounters *cnt, double *rgb, int32_t *ids, bool prof)
 {
@@ -1556,7 +1571,8 @@ static int launch_frame_direct(rt_hip_scene *s, const RenderArgs &A, bool stats,
   const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
   {
     ProfScope ps(prof ? s : nullptr, RT_HIP_K_FRAME_DIRECT, st);
-    if (!stats && !param && s->one_sample)
+    if (!frame_direct_one(s, stats) && !lum) return fail(RT_HIP_EINVAL, "internal: luminosity array missing");
+    if (frame_direct_one(s, stats))
       hipLaunchKernelGGL((k_frame_direct<false, false, true>), dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, order0, lum, cnt, gs, rgb, ids);
     else
       RT_LAUNCH_SP(k_frame_direct, stats, param, dim3(pblocks), st, s->dev, A, order0, lum, cnt, gs, rgb, ids);
@@ -1587,7 +1603,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   }
   const int cam_depth = A.cam.depth < 1 ? 1 : A.cam.depth;
   if (direct_rgb && cam_depth == 1 && s->dev.n_lights > 0 && !s->god && !s->keep_uv && !A.focusing && A.n_samples == 1) {
-    if (!s->one_sample) { rc = s->lum.ensure((size_t)n0 * s->dev.n_lights * sizeof(double)); if (rc) return rc; }
+    if (!frame_direct_one(s, stats)) { rc = s->lum.ensure((size_t)n0 * s->dev.n_lights * sizeof(double)); if (rc) return rc; }
     return launch_frame_direct(s, A, stats, st, n_waves, O.order0, (double *)s->lum.p, (RenderCounters *)s->counter.p, direct_rgb, direct_id, true);
   }
   rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
@@ -1691,7 +1707,7 @@ extern "C" int rt_hip_render_whitted_noalloc(rt_hip_scene *s, const rt_hip_camer
   if (A.pixel_count == 0 || n0 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
   // layout: [0, 256) counters | wave order workspace | luminosities (only for scenes that are not one light of one sample)
   const size_t ord_b = s->dev.has_tree ? ((order_bytes(n_waves) + 255) & ~(size_t)255) : 0;
-  const size_t lum_b = s->one_sample ? 0 : (size_t)n0 * s->dev.n_lights * sizeof(double);
+  const size_t lum_b = frame_direct_one(s, P->collect_stats != 0) ? 0 : (size_t)n0 * s->dev.n_lights * sizeof(double);
   const size_t need = 256 + ord_b + lum_b;
   if (need > RT_NOALLOC_SCRATCH_BYTES)
     return fail(RT_HIP_EINVAL, "rt_hip_render_whitted_noalloc: frame needs " + std::to_string(need) + " bytes of scratch, the fixed array holds " +
@@ -1770,12 +1786,12 @@ static int render_host(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_p
   RenderArgs A; int rc = fill_args(s, cam, P, &A); if (rc) return rc;
   if (!rgb) return fail(RT_HIP_EINVAL, "rgb is NULL");
   HIP_TRY(hipSetDevice(s->ctx->device));
-  size_t cb = A.n_out * ((!focusing && P->frame_format == RT_HIP_FRAME_BGR8) ? 3 : 24), ib = A.n_out * 4;
-  cb = (cb + 255) & ~(size_t)255;
+  const size_t cb = A.n_out * ((!focusing && P->frame_format == RT_HIP_FRAME_BGR8) ? 3 : 24), ib = A.n_out * 4;
+  const size_t id_off = (cb + 255) & ~(size_t)255;                             // the ids behind the colours, aligned
   if (A.n_out == 0) return RT_HIP_OK;
-  rc = s->staging.ensure(cb + ib); if (rc) return rc;
-  if (tile_sharded(A)) HIP_TRY(hipMemset(s->staging.p, 0, cb + ib));          // entries of edge super-tiles outside the image
-  double *d_rgb = (double *)s->staging.p; int32_t *d_id = (int32_t *)((char *)s->staging.p + cb);
+  rc = s->staging.ensure(id_off + ib); if (rc) return rc;
+  if (tile_sharded(A)) HIP_TRY(hipMemset(s->staging.p, 0, id_off + ib));      // entries of edge super-tiles outside the image
+  double *d_rgb = (double *)s->staging.p; int32_t *d_id = (int32_t *)((char *)s->staging.p + id_off);
   rc = focusing ? rt_hip_render_focusing_dev(s, cam, P, d_rgb, nullptr) : rt_hip_render_whitted_dev(s, cam, P, d_rgb, prim_id ? d_id : nullptr, nullptr);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());

@@ -130,7 +130,8 @@ RT_HD uint32_t rng_u32(uint64_t seed, uint32_t key0, uint32_t key1, uint32_t cou
   x = mix64(x ^ (0x8CB92BA72F3D8DD7ULL * ((uint64_t)counter + 1)));
   return (uint32_t)(x >> 32);
 }
-// counter = path(12) | light(4) | light-sample(14) | dim(2)
+// counter = path(12) | light(4) | light-sample(14) | dim(2).  path < 4096 is guaranteed by the callers: the render entry points refuse a
+// camera depth above 12 (a ray of level L has path < 2^(L+1)), so no two rays of a pixel sample share a stream
 RT_HD uint32_t rng_counter(uint32_t path, uint32_t light, uint32_t lsample, uint32_t dim)
 { return (path << 20) | ((light & 15u) << 16) | ((lsample & 0x3FFFu) << 2) | (dim & 3u); }
 // random(r, x) = 2 r (rand() % x) / x - r, Light.h:11, rand() := 31-bit draw

@@ -27,7 +27,7 @@ def main():
     rgb, _ = scenes.oracle_render_whitted(o3, dict(cam_args, depth=3), background=(200, 200, 200), seed=0)
     out["c1_metal_depth3_grid_rgb"] = rgb[grid]
     # C4: patch roots on a 60 x 34 ray grid
-    _, o4 = scenes.build_paper(gpu=False)
+    _, o4 = scenes.build_paper(gpu=False, mesh="icosahedron")
     c4 = dict(scenes.C4_CAMERA, res=10)
     rays4, W4, H4 = ob.OracleScene(0.0).camera_rays(scenes.oracle_camera(c4))
     ids4, pts4, uv4 = o4.trace_closest(rays4, use_bsp=True, want_uv=True)

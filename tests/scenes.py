@@ -1,120 +1,65 @@
-"""Scene builders shared by tests, smoke() and bench.py.
-
-Every builder adds the SAME objects, in the same order, to a product scene (ray_tracing_amd.Scene,
-i.e. the C++ host layer) and to an oracle scene (tests/oracle_bind.OracleScene), so that primitive
-ids agree.  Either side may be skipped (gpu=False / oracle=False).
-"""
-import math
-import os
-
+"""Scene builders of the tests: the workloads of ray_tracing_amd/workloads.py built on BOTH sides -- the product scene
+(ray_tracing_amd.Scene, the C++ host layer) and the checker's (tests/oracle_bind.OracleScene) -- with the same calls in
+the same order, so that primitive ids agree.  Either side may be skipped (gpu=False / oracle=False)."""
 import numpy as np
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-ICOSA_OBJ = os.path.join(HERE, "golden", "assets", "Icosahedron_Triangle.obj")
+from ray_tracing_amd import workloads as W
+from ray_tracing_amd.workloads import (C1_CAMERA, C2_CAMERA, C3_CAMERA, C4_CAMERA, C5_CAMERA, ROOM_CAMERA, TEX_CAMERA, PAPER_CTRL, PAPER_CENTER,  # noqa: F401
+                                       CUP2_PROFILES, APPLE_PROFILE, ICOSA_OBJ, WALL_LIGHT_OBJ, fnv_hash_ids, synth_texture, heightfield_triangles)
+
+
+def _stage(gpu, oracle):
+    """stage factory for the workload builders; remembers which side is which"""
+    def make(ambient):
+        sides, tags = [], []
+        if gpu:
+            import ray_tracing_amd as rta
+            sides.append((rta.Scene(ambient), rta.material)); tags.append("g")
+        if oracle:
+            import oracle_bind as ob
+            sides.append((ob.OracleScene(ambient), ob.material)); tags.append("o")
+        st = W.Stage(sides)
+        st.tags = tags
+        return st
+    return make
 
 
 class _Pair:
-    """forwards scene-building calls to both sides"""
+    """a two-sided stage for tests that add their own objects: .g / .o = product / oracle scene, .call / .mat as Stage"""
 
     def __init__(self, ambient, gpu=True, oracle=True):
-        self.g = self.o = None
-        if gpu:
-            import ray_tracing_amd as rta
-            self.rta = rta
-            self.g = rta.Scene(ambient)
-        if oracle:
-            import oracle_bind as ob
-            self.ob = ob
-            self.o = ob.OracleScene(ambient)
-
-    def mat(self, name):
-        return (self.rta.material(name) if self.g is not None else None, self.ob.material(name) if self.o is not None else None)
-
-    def call(self, fn, *args, mat=None, colour=None, **kw):
-        out = None
-        for side, m in ((self.g, mat[0] if mat else None), (self.o, mat[1] if mat else None)):
-            if side is None:
-                continue
-            a = list(args)
-            if mat is not None:
-                a += [m, colour]
-            out = getattr(side, fn)(*a, **kw)
-        return out
+        self._st = _stage(gpu, oracle)(ambient)
+        self.g, self.o = _go(self._st)
+        self.call, self.mat = self._st.call, self._st.mat
 
 
-def build_icosahedron(material="plastic", light="point_area", gpu=True, oracle=True, bsp=True, leaf_refine=None,
-                      extra_sphere=False, planes=True):
-    """C1: Layout3_Icosahedron (Layout.h:136-160) without textures.
-    light: 'point_area' = AddAreaLight((-10,20,20),1,0,1) (deterministic), 'area10' = Layout.h:155,
-           'point' / 'parallel' use the brute-force shadow rules of Light.h."""
-    P = _Pair(0.5, gpu, oracle)
-    plastic = P.mat("plastic")
-    if planes:      # planes=False: primary rays can leave the scene
-        P.call("add_plane", (0, 0, 0), (0, 0, 1), mat=plastic, colour=(255, 255, 255))
-        P.call("add_plane", (10, 0, 0), (-1, 0, 0), mat=plastic, colour=(0, 0, 0))
-    P.call("read_obj_triangle", ICOSA_OBJ, (0, -1, 0), 0.0015, mat=P.mat(material), colour=(241, 46, 24))
-    if extra_sphere:
-        P.call("add_sphere", (0.3, 0.6, 0.5), 0.5, mat=P.mat("glass"), colour=(161, 143, 81))
-        P.call("add_sphere", (-1.0, -2.2, 0.35), 0.35, mat=P.mat("mirror"), colour=(255, 255, 255))
-        P.call("add_circle", (0.5, 1.8, 0.4), (0.2, -0.5, 1), 0.6, mat=P.mat("porcelain"), colour=(20, 90, 200))
-    if bsp:
-        P.call("construct_bsp")
-    if light == "point_area":
-        P.call("add_area_light", (-10, 20, 20), 1.0, 0.0, 1)
-    elif light == "area10":
-        P.call("add_area_light", (-10, 20, 20), 1.0, 10.0, 10)
-    elif light == "area3":
-        P.call("add_area_light", (-10, 20, 20), 1.0, 10.0, 3)
-    elif light == "point":
-        P.call("add_point_light", (-10, 20, 20), 1.0)
-    elif light == "parallel":
-        P.call("add_parallel_light", (1, -1, -1), 1.0)
-    elif light == "two":
-        P.call("add_area_light", (-10, 20, 20), 0.6, 4.0, 2)
-        P.call("add_parallel_light", (1, 1, -1), 0.5)
-    if P.g is not None and leaf_refine is not None:
-        P.g.set_leaf_refine(leaf_refine)
-    return P.g, P.o
+def _go(stage):
+    d = {t: s for t, (s, _) in zip(stage.tags, stage.sides)}
+    return d.get("g"), d.get("o")
 
 
-C1_CAMERA = dict(view=(-10, 0, 1.5), eye=(1, 0, 0), left=(0, -1, 0), dist=10, hor=6.4, ver=4.8, res=100, depth=1)
+def build_icosahedron(material="plastic", light="point_area", gpu=True, oracle=True, **kw):
+    return _go(W.build_icosahedron(_stage(gpu, oracle), material=material, light=light, **kw))
 
 
-def heightfield_triangles(n_cells=708, half=5.0):
-    """C2 mesh: heightfield on [-half,half]^2, n_cells per side, 2 triangles per cell, order i-major,
-    j-minor, (P(i,j),P(i+1,j),P(i+1,j+1)) then (P(i,j),P(i+1,j+1),P(i,j+1)).  Height = the surveyor's probe
-    function z = 0.6 sin1.7x cos2.3y + 0.25 sin(5.1x+1.3) sin(4.3y+0.7) + 0.05 sin23x cos19y (host libm)."""
-    idx = np.arange(n_cells + 1, dtype=np.float64)
-    xs = -half + (2 * half) * idx / n_cells
-    X, Y = np.meshgrid(xs, xs, indexing="ij")
-    Z = 0.6 * np.sin(1.7 * X) * np.cos(2.3 * Y) + 0.25 * np.sin(5.1 * X + 1.3) * np.sin(4.3 * Y + 0.7) + 0.05 * np.sin(23 * X) * np.cos(19 * Y)
-    Pnt = np.stack([X, Y, Z], axis=-1)
-    p00 = Pnt[:-1, :-1]
-    p10 = Pnt[1:, :-1]
-    p11 = Pnt[1:, 1:]
-    p01 = Pnt[:-1, 1:]
-    t1 = np.stack([p00, p10, p11], axis=2)
-    t2 = np.stack([p00, p11, p01], axis=2)
-    tris = np.stack([t1, t2], axis=2)          # (n, n, 2, 3, 3)
-    return np.ascontiguousarray(tris.reshape(-1, 9))
+def build_heightfield(n_cells=708, gpu=True, oracle=True, **kw):
+    return _go(W.build_heightfield(_stage(gpu, oracle), n_cells, **kw))
 
 
-C2_CAMERA = dict(view=(-12, -9, 7), eye=(12, 9, -7), left=(9, -12, 0), dist=20, hor=19.2, ver=10.8, res=100, depth=1)
+def build_paper(gpu=True, oracle=True, **kw):
+    return _go(W.build_paper(_stage(gpu, oracle), **kw))
 
 
-def build_heightfield(n_cells=708, gpu=True, oracle=True, leaf_refine=None, max_obj_num=0, light=True):
-    """C2: ground plane z=-1 (id 0) + heightfield, plastic, point-like area light."""
-    P = _Pair(0.5, gpu, oracle)
-    plastic = P.mat("plastic")
-    P.call("add_plane", (0, 0, -1), (0, 0, 1), mat=plastic, colour=(200, 200, 200))
-    tris = heightfield_triangles(n_cells)
-    P.call("add_triangles", tris, mat=plastic, colour=(90, 160, 60))
-    P.call("construct_bsp", max_obj_num, 0)
-    if light:
-        P.call("add_area_light", (-10, 20, 20), 1.0, 0.0, 1)
-    if P.g is not None and leaf_refine is not None:
-        P.g.set_leaf_refine(leaf_refine)
-    return P.g, P.o
+def build_wine(gpu=True, oracle=True, **kw):
+    return _go(W.build_wine(_stage(gpu, oracle), **kw))
+
+
+def build_room(gpu=True, oracle=True, **kw):
+    return _go(W.build_room(_stage(gpu, oracle), **kw))
+
+
+def build_textured(gpu=True, oracle=True, **kw):
+    return _go(W.build_textured(_stage(gpu, oracle), **kw))
 
 
 def oracle_camera(cam_args):
@@ -125,163 +70,3 @@ def oracle_camera(cam_args):
 
 def oracle_render_whitted(orc_scene, cam_args, background=(0, 0, 0), seed=0, **kw):
     return orc_scene.render_whitted(oracle_camera(cam_args), background=background, seed=seed, **kw)
-
-
-def fnv_hash_ids(ids):
-    """the hash of SURVEY 8c over (id+1) in raster order"""
-    h = 1469598103934665603
-    M = (1 << 64) - 1
-    for i in np.asarray(ids).tolist():
-        h ^= (i + 1) & 0xFFFFFFFF
-        h = (h * 1099511628211) & M
-    return "%016x" % h
-
-
-# ---- parametric objects (SURVEY 8d C4 / C5 geometry, untextured) ---------------------------------------------
-PAPER_CTRL = [[(-2, 6, 9), (-1, 2, 9), (-1, -2, 9), (-2, -6, 9)],
-              [(-1, 6, 3), (0, 2, 3), (0, -2, 3), (-1, -6, 3)],
-              [(-1, 6, -3), (0, 2, -2), (0, -2, -3), (-1, -6, -3)],
-              [(-2, 6, -9), (-1, 2, -9), (-1, -2, -9), (-2, -6, -9)]]      # Layout.h:113-117
-PAPER_CENTER = (20, 25, 17)                                               # Layout.h:118
-
-C4_CAMERA = dict(view=(-10, 20, 20), eye=(1, 0, 0), left=(-0.8, -1, 0), dist=5, hor=6, ver=3.375, res=320, depth=2)
-
-
-def build_paper(gpu=True, oracle=True, bsp=True, mesh=True, material="rubber"):
-    """C4: Layout2_WallAndPaper (Layout.h:104-133) untextured: wall plane, the bicubic "paper" patch and a
-    triangle mesh beside it (the icosahedron asset stands in for WallLight.obj), parallel light (1,-1,-1) L=2."""
-    P = _Pair(0.05, gpu, oracle)
-    P.call("add_plane", (20, 0, 0), (-1, 0, 0), mat=P.mat("rubber"), colour=(120, 120, 120))
-    P.call("add_bezier", PAPER_CTRL, PAPER_CENTER, mat=P.mat(material), colour=(255, 255, 255))
-    if mesh:
-        P.call("read_obj_triangle", ICOSA_OBJ, (18.5, 13, 20), 0.004, mat=P.mat("metal"), colour=(50, 50, 60))
-    P.call("add_parallel_light", (1, -1, -1), 2.0)
-    if bsp:
-        P.call("construct_bsp")
-    return P.g, P.o
-
-
-CUP2_PROFILES = [([(2, 0.2), (0.2, 0.2), (0.2, 2.2), (0.2, 4.2)], 50),          # Object_Cup2, Layout.h:190-235
-                 ([(0.2, 4.2), (0.2, 6.2), (2, 6.2), (1.7, 10.2)], 50),
-                 ([(1.6, 10.2), (1.65, 8.2), (1.3, 6.2), (0, 6.2)], 50),
-                 ([(2, 0), (2.1, 0.1), (2, 0.2)], 10),
-                 ([(1.7, 10.2), (1.65, 10.3), (1.6, 10.2)], 10)]
-
-C5_CAMERA = dict(view=(-23.5, 27.5, 24), eye=(2.9, -3, -2), left=(-1, -1, 0), dist=15, hor=8, ver=4.5, res=240, depth=8)
-
-
-def build_wine(gpu=True, oracle=True, cups=((-2, -2, 0),), light="point", cup_material="glass", u_samples=None):
-    """C5 geometry: Layout5_Wine (Layout.h:237-300) untextured and WITHOUT a tree: three planes, per cup the
-    five surfaces of revolution of Object_Cup2, the wine surface (uRange 0.7) and its circle lid."""
-    e = 1e-8
-    P = _Pair(0.5, gpu, oracle)
-    P.call("add_plane", (0, 0, 0), (0, 0, 1), mat=P.mat("rubber"), colour=(140, 100, 60))
-    P.call("add_plane", (10, 0, 0), (-1, 0, 0), mat=P.mat("plastic"), colour=(90, 90, 110))
-    P.call("add_plane", (0, -10, 0), (0, 1, 0), mat=P.mat("plastic"), colour=(90, 110, 90))
-    wine = [(0, 6.2 - 10 * e), (1.3 + 10 * e, 6.2 - 10 * e), (1.65 + 10 * e, 8.2 - 10 * e), (1.6 + 10 * e, 10.2 - 10 * e)]
-    for c in cups:
-        for prof, ns in CUP2_PROFILES:
-            P.call("add_rotational", prof, c, (u_samples or ns), 1.0, mat=P.mat(cup_material), colour=(155, 155, 155))
-        P.call("add_rotational", wine, c, (u_samples or 50), 0.7, mat=P.mat("ice"), colour=(151, 57, 29))
-        # CCircle at the curve point of u = 0.7 (Layout.h:262-264), de Casteljau on the host
-        pts = np.array(wine, dtype=np.float64)
-        t = 0.7
-        while len(pts) > 1:
-            pts = pts[:-1] * (1 - t) + pts[1:] * t
-        P.call("add_circle", (c[0], c[1], float(pts[0][1])), (0, 0, 1), float(pts[0][0]) + 10 * e, mat=P.mat("ice"), colour=(151, 57, 29))
-    if light == "point":
-        P.call("add_point_light", (-10, 25, 25), 2.0)
-    elif light == "area":
-        P.call("add_area_light", (-10, 25, 25), 2.0, 2.0, 2)
-    elif light == "area5":                     # SURVEY 8d C5: AddAreaLight((-10,25,25), 2, 2, 5)
-        P.call("add_area_light", (-10, 25, 25), 2.0, 2.0, 5)
-    return P.g, P.o
-
-
-ROOM_CAMERA = dict(view=(-10, 0, 2.5), eye=(1, 0, 0), left=(0, -1, 0), dist=10, hor=8, ver=6, res=100, depth=1)   # Layout.h:320
-
-
-def build_room(gpu=True, oracle=True, mirror=True):
-    """Layout6_Room (Layout.h:302-323) with a synthetic corridor: Corridor_Triangle.obj is one of the blobs missing from
-    the reference checkout (.MISSING_LARGE_BLOBS), so a floor, a side wall with a window gap and the icosahedron mesh
-    stand in for it.  Light shafts come from an XZ rectangle at y = 6 towards (1,-2,-1) as in Layout.h:317-318."""
-    P = _Pair(0.1, gpu, oracle)
-    plastic = P.mat("plastic")
-    P.call("add_plane", (50, 0, 0), (-1, 0, 0), mat=plastic, colour=(90, 90, 120))
-    def quad(a, b, c, d, mat, colour):
-        P.call("add_triangle", [a, b, c], None, mat=mat, colour=colour)
-        P.call("add_triangle", [a, c, d], None, mat=mat, colour=colour)
-    quad((-12, -8, 0), (30, -8, 0), (30, 8, 0), (-12, 8, 0), plastic, (241, 46, 24))             # floor
-    quad((-12, 5, 0), (2, 5, 0), (2, 5, 8), (-12, 5, 8), plastic, (200, 200, 200))               # wall, left of the window
-    quad((6, 5, 0), (30, 5, 0), (30, 5, 8), (6, 5, 8), plastic, (200, 200, 200))                 # wall, right of the window
-    quad((2, 5, 0), (6, 5, 0), (6, 5, 1), (2, 5, 1), plastic, (200, 200, 200))                   # sill
-    P.call("read_obj_triangle", ICOSA_OBJ, (9, -2, 0), 0.003, mat=P.mat("metal" if mirror else "plastic"), colour=(241, 46, 24))
-    P.call("construct_bsp")
-    P.call("add_area_light", (-10, 20, 20), 2.0, 10.0, 2)
-    return P.g, P.o
-
-
-# ---- textures (SURVEY 8f N1) and RotationalSurfaceToMesh (N3) ------------------------------------------------------
-def synth_texture(rows, cols, seed, kind="colour"):
-    """deterministic (rows, cols, 3) uint8 B,G,R images standing in for the reference's JPEG assets: 'colour' = blocks
-    of random colours over a gradient, 'bump' = a normal map whose blue (N) channel stays dominant"""
-    rng = np.random.default_rng(seed)
-    r = np.arange(rows)[:, None]; c = np.arange(cols)[None, :]
-    if kind == "colour":
-        blocks = rng.integers(30, 255, size=((rows + 7) // 8, (cols + 7) // 8, 3))
-        img = np.kron(blocks, np.ones((8, 8, 1), dtype=np.int64))[:rows, :cols]
-        img = (img * 0.7 + 0.3 * ((r * 255 // max(1, rows - 1) + c * 255 // max(1, cols - 1)) // 2)[..., None]).astype(np.uint8)
-        return np.ascontiguousarray(img)
-    img = np.zeros((rows, cols, 3), dtype=np.uint8)
-    img[..., 0] = 200 + rng.integers(0, 55, size=(rows, cols))                       # B -> N
-    img[..., 1] = (127.5 + 90 * np.sin(r * 0.7) * np.cos(c * 0.45)).astype(np.uint8)  # G -> tangent
-    img[..., 2] = (127.5 + 90 * np.cos(r * 0.31 + c * 0.53)).astype(np.uint8)         # R -> bitangent
-    return img
-
-
-APPLE_PROFILE = [(0, 0.3), (2.2, -0.9), (2.6, 2.4), (0.05, 2.0)]       # a closed-ish blob profile (radius, height)
-TEX_CAMERA = dict(view=(-14, 3, 7), eye=(1, -0.1, -0.3), left=(0, -1, 0), dist=10, hor=9.6, ver=7.2, res=40, depth=3)
-
-
-def build_textured(gpu=True, oracle=True, bsp=True, light="point_area"):
-    """every texture path of Object.h on one stage: textured + bump-mapped planes (Layout.h:76-87), textured and
-    bump-mapped spheres (Layout.h:171-175), a textured bump-mapped Bezier patch (Layout.h:121-122), a textured
-    bump-mapped surface of revolution, a textured mesh from RotationalSurfaceToMesh_Texture (Layout.h:60), a plain
-    RotationalSurfaceToMesh, a textured triangle with explicit textureCoord, a bump-mapped triangle (no tangent frame,
-    Object.h:63-64) and a textured circle (default UV, Object.h:61)"""
-    P = _Pair(0.3, gpu, oracle)
-    t_floor = P.call("add_texture_image", synth_texture(96, 80, 1))
-    t_wall = P.call("add_texture_image", synth_texture(64, 64, 2))
-    t_ball = P.call("add_texture_image", synth_texture(50, 100, 3))
-    t_skin = P.call("add_texture_image", synth_texture(40, 60, 4))
-    b_floor = P.call("add_texture_image", synth_texture(48, 48, 5, "bump"))
-    b_ball = P.call("add_texture_image", synth_texture(32, 64, 6, "bump"))
-    plastic, metal, porcelain = P.mat("plastic"), P.mat("metal"), P.mat("porcelain")
-    floor = P.call("add_plane", (0, 0, 0), (0, 0, 1), mat=porcelain, colour=(255, 255, 255))
-    P.call("add_texture", floor, t_floor, 5.0); P.call("add_bump_texture", floor, b_floor, 3.0)
-    wall = P.call("add_plane", (12, 0, 0), (-1, 0, 0), mat=plastic, colour=(255, 255, 255))
-    P.call("add_texture", wall, t_wall, 2.0); P.call("add_bump_texture", wall, b_floor, 5.0)
-    side = P.call("add_plane", (0, -9, 0), (0.3, 1, 0.1), mat=plastic, colour=(255, 255, 255))      # a tilted normal: the other u0 branches
-    P.call("add_texture", side, t_wall, 7.0)
-    s1 = P.call("add_sphere", (2, 5, 1.5), 1.5, mat=plastic, colour=(255, 255, 255))
-    P.call("add_texture", s1, t_ball)
-    s2 = P.call("add_sphere", (0, 1.5, 1.2), 1.2, mat=metal, colour=(230, 200, 120))
-    P.call("add_bump_texture", s2, b_ball)
-    ctrl = (np.array(PAPER_CTRL, dtype=np.float64) * 0.3).tolist()
-    paper = P.call("add_bezier", ctrl, (9, -3, 4), mat=P.mat("rubber"), colour=(255, 255, 255))
-    P.call("add_texture", paper, t_skin); P.call("add_bump_texture", paper, b_ball)
-    cup = P.call("add_rotational", [(1.2, 0), (0.4, 1.0), (1.6, 2.0), (1.1, 3.2)], (4, -2, 0), 20, 1.0, mat=porcelain, colour=(255, 255, 255))
-    P.call("add_texture", cup, t_skin); P.call("add_bump_texture", cup, b_ball)
-    P.call("rotational_surface_to_mesh", APPLE_PROFILE, 5, 15, (1, -5, 0.9), mat=plastic, colour=(255, 255, 255), tex=t_ball)
-    P.call("rotational_surface_to_mesh", APPLE_PROFILE, 4, 9, (6, 4, 0.9), mat=metal, colour=(80, 160, 90))
-    tri = P.call("add_triangle_tex", [(3, 0, 0.02), (7, 0.5, 0.02), (5, 3, 2.5)], None, [(0, 0), (39, 0), (20, 59)], mat=plastic, colour=(255, 255, 255))
-    P.call("add_texture", tri, t_skin); P.call("add_bump_texture", tri, b_ball)
-    circ = P.call("add_circle", (-2, -2.5, 0.6), (0.1, 0.2, 1), 1.3, mat=plastic, colour=(10, 10, 10))
-    P.call("add_texture", circ, t_wall)
-    if bsp:
-        P.call("construct_bsp")
-    if light == "point_area":
-        P.call("add_area_light", (-10, 12, 20), 1.2, 0.0, 1)
-    elif light == "area":
-        P.call("add_area_light", (-10, 12, 20), 1.2, 4.0, 2)
-    return P.g, P.o

@@ -29,7 +29,7 @@ def test_oracle_reproduces_golden():
     assert (ids == _c1_ids()).all()
     grid = G["c1_grid"]
     assert np.abs(np.linalg.norm(pts[grid] - rays[grid, :3], axis=1) - G["c1_grid_t"]).max() < 1e-12
-    _, o4 = scenes.build_paper(gpu=False)
+    _, o4 = scenes.build_paper(gpu=False, mesh="icosahedron")
     rays4, _, _ = ob.OracleScene(0.0).camera_rays(scenes.oracle_camera(dict(scenes.C4_CAMERA, res=10)))
     ids4, pts4, uv4 = o4.trace_closest(rays4, use_bsp=True, want_uv=True)
     assert (ids4 == G["c4_ids"]).all() and np.abs(uv4 - G["c4_uv"]).max() < 1e-12
@@ -102,7 +102,7 @@ def test_gpu_reproduces_golden(ctx):
     ref = G["c1_metal_depth3_grid_rgb"]
     assert (np.abs(cam.rgb()[grid] - ref) / np.maximum(1.0, np.abs(ref))).max() < 1e-3
     # C4 patch roots
-    g4, _ = scenes.build_paper(oracle=False)
+    g4, _ = scenes.build_paper(oracle=False, mesh="icosahedron")
     rays4, _, _ = ob.OracleScene(0.0).camera_rays(scenes.oracle_camera(dict(scenes.C4_CAMERA, res=10)))
     h4 = g4.first_inter_pt(ctx, rays4, use_tree=True)
     assert (h4["prim_id"] == G["c4_ids"]).all()

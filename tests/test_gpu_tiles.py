@@ -138,3 +138,29 @@ def test_two_processes_render_one_frame(ctx, tmp_path):
     assert np.abs(res["ppm_picture"].astype(int) - pm.picture().astype(int)).max() <= 1
     info = pm.info()
     assert tuple(res["ppm_census"]) == (info["photon_segments"], info["photon_hits"])
+
+
+@pytest.mark.parametrize("scene_kind", ["one_sample", "param_one_light", "two_lights"])
+def test_statistics_kernels_give_the_same_frame(ctx, scene_kind):
+    """collect_stats != 0 runs the counting instantiations of the kernels; for a depth-1 frame that is the general
+    k_frame_direct (with its luminosity array) also where the plain call takes the loop-free one-light kernel"""
+    import torch
+    import ray_tracing_amd as rta
+    if scene_kind == "param_one_light":
+        g, _ = scenes.build_wine(oracle=False, light="point")
+        cam = rta.Camera(**dict(scenes.C5_CAMERA, res=12, depth=1))
+    else:
+        g, _ = scenes.build_icosahedron(light="point_area" if scene_kind == "one_sample" else "two", oracle=False)
+        cam = rta.Camera(**dict(scenes.C1_CAMERA, res=50))
+    n = cam.width * cam.height
+    outs = []
+    for stats in (0, 1, 0):
+        rgb = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+        p = rta.Params(background=(200, 200, 200), collect_stats=stats)
+        ctx.stats(reset=True)
+        rta.check(rta.hip.rt_hip_render_whitted_dev(g.device(ctx), cam.raw, p, C.c_void_p(rgb.data_ptr()), None, None))
+        torch.cuda.synchronize()
+        st = ctx.stats(reset=True)
+        assert (st["rays"] > 0) == bool(stats)
+        outs.append(rgb.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])

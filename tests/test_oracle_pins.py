@@ -31,6 +31,18 @@ def test_c1_hit_id_hash_matches_survey():
 def test_c2_tree_statistics_match_survey():
     """the reference's own BSP build of the 1,002,528-triangle heightfield gave 67,281 nodes,
     33,641 leaves (4,450 empty), 1,832,852 leaf references, max depth 20, max leaf 99."""
-    _, o = scenes.build_heightfield(708, gpu=False)
+    _, o = scenes.build_heightfield(708, gpu=False, libm_free=False)     # the surveyor's probe mesh (sin / cos heights)
     st, _ = o.tree_stats()
     assert st[:6] == [67281, 33641, 4450, 1832852, 20, 99]
+
+
+def test_c2_bench_mesh_tree():
+    """the C2 mesh that bench.py and the full-size parity tests use: same shape, heights from + - x floor only
+    (ray_tracing_amd/workloads.py), so it is bit-identical on every host.  The oracle's build of it (BSPTree.h:58-109
+    restated) gives these figures; the product's host build must agree with them node for node."""
+    g, o = scenes.build_heightfield(708)
+    st, box = o.tree_stats()
+    assert st[:6] == [67915, 33958, 4536, 1849912, 20, 99]
+    gs, gbox = g.tree_stats()
+    assert gs == st and gbox == box
+    assert g.num_objects == o.num_objects == 1002529
