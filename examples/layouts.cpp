@@ -5,6 +5,12 @@
 //   layouts apples   <out.ppm> [resolution]                                     Layout1_Apples-like: textured mesh from
 //                                                                               RotationalSurfaceToMesh_Texture, textured +
 //                                                                               bump-mapped planes, anti-aliased render
+//   layouts wine     <out.ppm> [resolution] [times] [photonNum] [oversampleTimes]   Layout5_Wine, Layout.h:237-300: three cups,
+//                                                                               Render_PhotonMapper_Antialiasing (untextured)
+//   layouts room     <Icosahedron_Triangle.obj> <out.ppm> [resolution] [oversampleTimes]
+//                                                                               Layout6_Room, Layout.h:302-323: Render_RayTracer_GodRay_
+//                                                                               Antialiasing; Corridor_Triangle.obj is missing from the
+//                                                                               reference checkout, a few walls and a mesh stand in
 //
 // Textures: the reference reads JPEG through OpenCV; here the images are synthetic (or binary PPM via Image::ReadPPM).
 #include "../ray_tracing_amd/host/rt_host.hpp"
@@ -71,13 +77,89 @@ static int apples(int argc, char **argv)
   return 0;
 }
 
+// Object_Cup2, Layout.h:190-235
+static void Object_Cup2(Scene &scene, Point3D center, const Material &material, Colour colour)
+{
+  scene.AddRotationalObject({{2, 0.2}, {0.2, 0.2}, {0.2, 2.2}, {0.2, 4.2}}, center, material, colour, 50);
+  scene.AddRotationalObject({{0.2, 4.2}, {0.2, 6.2}, {2, 6.2}, {1.7, 10.2}}, center, material, colour, 50);
+  scene.AddRotationalObject({{1.6, 10.2}, {1.65, 8.2}, {1.3, 6.2}, {0, 6.2}}, center, material, colour, 50);
+  scene.AddRotationalObject({{2, 0}, {2.1, 0.1}, {2, 0.2}}, center, material, colour, 10);
+  scene.AddRotationalObject({{1.7, 10.2}, {1.65, 10.3}, {1.6, 10.2}}, center, material, colour, 10);
+}
+
+static int wine(int argc, char **argv)
+{
+  if (argc < 3) { std::cerr << "usage: layouts wine <out.ppm> [resolution] [times] [photonNum] [oversampleTimes]\n"; return 2; }
+  const int res = argc > 3 ? std::atoi(argv[3]) : 100, times = argc > 4 ? std::atoi(argv[4]) : 30;
+  const uint32_t photonNum = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 50000, os = argc > 6 ? (uint32_t)std::atoi(argv[6]) : 100;
+  const double eps = 1e-8;
+  Context gpu(0);
+  Scene scene(0.5);                                                                                     // Layout.h:239
+  scene.AddInftyPlane({0, 0, 0}, {0, 0, 1}, Material(_RUBBER_), Colour(140, 100, 60));                  // :241-251 (texture_wood / texture6 left out)
+  scene.AddInftyPlane({10, 0, 0}, {-1, 0, 0}, Material(_PLASTIC_), Colour(90, 90, 110));
+  scene.AddInftyPlane({0, -10, 0}, {0, 1, 0}, Material(_PLASTIC_), Colour(90, 110, 90));
+  const std::vector<std::array<double, 2>> wineCurve = {{0, 6.2 - 10 * eps}, {1.3 + 10 * eps, 6.2 - 10 * eps}, {1.65 + 10 * eps, 8.2 - 10 * eps},
+                                                        {1.6 + 10 * eps, 10.2 - 10 * eps}};             // bezierCurve1, :254-258
+  RotationalSurface bezierCurve1; for (auto &c : wineCurve) bezierCurve1.AddControlPt(c[0], c[1]);
+  struct Cup { Point3D center; double uRange; Colour wine; };
+  const Cup cups[3] = {{{-2, -2, 0}, 0.7, Colour(151, 57, 29)}, {{2.2, 2.2, 0}, 0.5, Colour(100, 25, 30)}, {{5, 5, 0}, 0.8, Colour(100, 25, 30)}};
+  for (const Cup &c : cups) {                                                                           // :253-286 (rObj2 and rObj3 rotate bezierCurve1 too)
+    Object_Cup2(scene, c.center, Material(_GLASS_), Colour(155, 155, 155));
+    scene.AddRotationalObject(wineCurve, c.center, Material(_ICE_), c.wine, 50, c.uRange);
+    const auto pt = bezierCurve1.Point2D(c.uRange, 0, bezierCurve1.degree());                           // CBezierCurve::Point2D(t), Bezier.h:27
+    scene.AddCircle({c.center.x, c.center.y, pt[1]}, {0, 0, 1}, pt[0] + 10 * eps, Material(_ICE_), c.wine);
+  }
+  scene.AddAreaLight({-10, 25, 25}, 2, 2, 5);                                                           // :289
+  Camera camera({-23.5, 27.5, 24}, {2.9, -3, -2}, {-1, -1, 0}, 15, 8, 6, res, 8);                       // :291
+  camera.seed = 1;
+  camera.Render_PhotonMapper_Antialiasing(gpu, scene, times, Colour(0, 0, 0), photonNum, os);          // :299
+  camera.WritePPM(argv[2]);
+  size_t masked = 0; for (uint8_t m : camera.edge_mask()) masked += m;
+  std::cout << camera.width() << "x" << camera.height() << ", " << scene.NumObjects() << " objects, " << masked << " pixels re-sampled\n";
+  return 0;
+}
+
+static int room(int argc, char **argv)
+{
+  if (argc < 4) { std::cerr << "usage: layouts room <obj> <out.ppm> [resolution] [oversampleTimes]\n"; return 2; }
+  const int res = argc > 4 ? std::atoi(argv[4]) : 100;
+  const uint32_t os = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 100;
+  Context gpu(0);
+  Scene scene(0.1);                                                                                     // Layout.h:304
+  scene.AddInftyPlane({50, 0, 0}, {-1, 0, 0}, Material(_PLASTIC_), Colour(90, 90, 120));                // :306-308
+  auto quad = [&](Point3D a, Point3D b, Point3D c, Point3D d, Colour col) {
+    const Point3D t1[3] = {a, b, c}, t2[3] = {a, c, d};
+    scene.AddTriangle(t1, nullptr, Material(_PLASTIC_), col); scene.AddTriangle(t2, nullptr, Material(_PLASTIC_), col);
+  };
+  // stand-in for ./ObjFiles/Corridor_Triangle.obj (:310): a floor, a wall with a window gap under the light source, a mesh
+  quad({-12, -8, 0}, {30, -8, 0}, {30, 8, 0}, {-12, 8, 0}, Colour(241, 46, 24));
+  quad({-12, 5, 0}, {2, 5, 0}, {2, 5, 8}, {-12, 5, 8}, Colour(200, 200, 200));
+  quad({6, 5, 0}, {30, 5, 0}, {30, 5, 8}, {6, 5, 8}, Colour(200, 200, 200));
+  quad({2, 5, 0}, {6, 5, 0}, {6, 5, 1}, {2, 5, 1}, Colour(200, 200, 200));
+  scene.ReadObjFile_Triangle(argv[2], {9, -2, 0}, 0.003, Material(_METAL_), Colour(241, 46, 24));
+  scene.ConstructBSPTree();                                                                             // :313
+  scene.AddAreaLight({-10, 20, 20}, 2, 10, 2);                                                          // :315 (10 x 10 samples there)
+  GodRay godRay(gpu, scene, Colour(155, 155, 50), 9);                                                   // :317
+  const double mn[2] = {-3, 0}, mx[2] = {9, 10};
+  godRay.AddAreaLightSource_XZ(6, mn, mx, 0.4, {1, -2, -1});                                            // :318 (interval 0.1 there)
+  Camera camera({-10, 0, 2.5}, {1, 0, 0}, {0, -1, 0}, 10, 8, 6, res, 1);                                // :320
+  camera.seed = 9;
+  camera.Render_RayTracer_GodRay_Antialiasing(godRay, Colour(20, 20, 30), os);                         // :321
+  camera.WritePPM(argv[3]);
+  size_t masked = 0; for (uint8_t m : camera.edge_mask()) masked += m;
+  std::cout << camera.width() << "x" << camera.height() << ", " << masked << " pixels re-sampled\n";
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   try {
     const std::string what = argc > 1 ? argv[1] : "";
     if (what == "focusing") return focusing(argc, argv);
     if (what == "apples") return apples(argc, argv);
-    std::cerr << "usage: layouts focusing|apples ...\n";
+    if (what == "wine") return wine(argc, argv);
+    if (what == "room") return room(argc, argv);
+    std::cerr << "usage: layouts focusing|apples|wine|room ...\n";
     return 2;
   } catch (const std::exception &e) { std::cerr << "error: " << e.what() << "\n"; return 1; }
 }

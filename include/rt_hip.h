@@ -304,6 +304,15 @@ int rt_hip_last_aa_edges(rt_hip_scene *scene, uint64_t *n);
 typedef struct rt_hip_ppm rt_hip_ppm;
 int rt_hip_ppm_begin(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params, uint32_t photon_num, uint32_t times,
                      rt_hip_ppm **out);
+/* CCamera::Render_PhotonMapper_Antialiasing (Camera.h:315-423) up to PhotonMappingPass: the maps and edge mask of
+ * rt_hip_render_antialiasing, then the eye pass in which a masked pixel sends oversample_times jittered rays through RayTracingPass,
+ * all of them depositing hit points on that pixel (:384-389), and the other pixels one ray (:393-394).  The passes then add into
+ * the CV_32SC3 picture (PhotonMapper.h:365-367) and rt_hip_ppm_resolve divides a masked pixel's sums by oversample_times before the
+ * saturating add (Camera.h:414-418).  Everything after begin (trace / update / pass / resolve / checkpoint) is the same object.
+ * aa == NULL: the constants of Camera.h:77-82. */
+int rt_hip_ppm_begin_aa(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params, const rt_hip_aa_params *aa,
+                        uint32_t photon_num, uint32_t times, rt_hip_ppm **out);
+int rt_hip_ppm_edge_mask(rt_hip_ppm *ppm, uint8_t *mask /* W*H: 1 = re-sampled pixel; all 0 for rt_hip_ppm_begin */);
 int rt_hip_ppm_info(rt_hip_ppm *ppm, uint64_t *n_hitpoints, uint64_t *photons_per_pass, uint64_t *photon_segments, uint64_t *photon_hits);
 int rt_hip_ppm_trace(rt_hip_ppm *ppm, uint32_t pass_index, uint64_t photon_first, uint64_t photon_count, void *stream);
 int rt_hip_ppm_accumulators(rt_hip_ppm *ppm, double **d_acc, uint64_t *n_doubles);   /* 4 per hit point: M, tau R, G, B */
@@ -336,6 +345,13 @@ int rt_hip_render_godray(rt_hip_scene *scene, rt_hip_godray *g, const rt_hip_cam
                          int32_t *prim_id);
 int rt_hip_render_godray_dev(rt_hip_scene *scene, rt_hip_godray *g, const rt_hip_camera *cam, const rt_hip_params *params, double *d_rgb,
                              int32_t *d_prim_id, void *stream);
+/* CCamera::Render_RayTracer_GodRay_Antialiasing (Camera.h:450-537) after PhotonMappingPass: maps and mask from the plain RayTracer
+ * (:483), masked pixels re-sampled through CGodRay::RayTracingPass (:516-523), the others one such ray (:527-528); rgb, edge_mask and
+ * the pixel shard as in rt_hip_render_antialiasing */
+int rt_hip_render_godray_antialiasing(rt_hip_scene *scene, rt_hip_godray *g, const rt_hip_camera *cam, const rt_hip_params *params,
+                                      const rt_hip_aa_params *aa, double *rgb, uint8_t *edge_mask);
+int rt_hip_render_godray_antialiasing_dev(rt_hip_scene *scene, rt_hip_godray *g, const rt_hip_camera *cam, const rt_hip_params *params,
+                                          const rt_hip_aa_params *aa, double *d_rgb, uint8_t *d_edge_mask, void *stream);
 int rt_hip_godray_destroy(rt_hip_godray *g);
 
 /* ---- multi-GPU exchange: one process per GPU, RCCL over xGMI behind the ABI.  The reference has no counterpart: its only

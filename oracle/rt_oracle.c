@@ -1150,7 +1150,7 @@ static col_t local_illumination(orc_scene *s, ray_t ray, inter_t in, const rng_c
 
 /* CHitpoint, PhotonMapper.h:14-26 (+ the position in the ray tree, used as a key by the tests) */
 typedef struct { v3 pt, norm, omega; int h, v; double wgt, R, N, M; col_t tau; uint32_t pixel, path; } hitpoint_t;
-typedef struct { hitpoint_t *a; size_t n, cap; int W; } hp_sink_t;
+typedef struct { hitpoint_t *a; size_t n, cap; int W; int key_sample; } hp_sink_t;   /* key_sample: path key = (sample << 12) | path (anti-aliased eye pass) */
 static _Thread_local hp_sink_t *tl_hp = NULL;      /* non-NULL: ray_tracer is CPhotonMapper::RayTracingPass (PhotonMapper.h:159-220) */
 
 struct orc_godray;
@@ -1180,7 +1180,7 @@ static col_t ray_tracer(orc_scene *s, ray_t ray, int depth, double weight, col_t
     hp->omega = ray.d;
     hp->h = (int)(g.pixel % (uint32_t)k->W); hp->v = (int)(g.pixel / (uint32_t)k->W);
     hp->wgt = weight; hp->R = 1; hp->N = 0; hp->M = 0; hp->tau = C3(0, 0, 0);      /* R_initial, :10, :25 */
-    hp->pixel = g.pixel; hp->path = g.path;
+    hp->pixel = g.pixel; hp->path = k->key_sample ? ((g.sample << 12) | g.path) : g.path;
   }
   if (depth > 1) {
     int total_reflect = 0;
@@ -1359,15 +1359,12 @@ static double laplace_at(const double *m, int W, int H, int v, int h)       /* C
  * Camera.h:109) counts with depth = Dist(inftyPt, viewPt), a zero normal and type -1.
  * RNG keys: lens point (pixel, lens sample i, path 0, stream 0, dims 0..2); picture-plane jitter (pixel,
  * ray index i * oversampleTimes + j, path 0, stream 1, dims 0..2); the ray tree below uses (pixel, ray index). */
-void orc_render_antialiasing(orc_scene *s, const orc_camera *c, const double aa[6], int focusing, double radius, int spp,
-                             const double bg[3], uint64_t seed, double *rgb, unsigned char *edge_mask, int threads)
+/* the maps of Camera.h:89-121 (207-232, 321-352, 456-487): depth, normal, type (and, unless focusing, the RayTracer colour) per pixel */
+static double *aa_maps(orc_scene *s, const cam_t *kp, int focusing, col_t bgc, uint64_t seed, int threads)
 {
-  cam_t k = cam_init(c);
+  const cam_t k = *kp;
   const int W = k.W, H = k.H;
   const size_t total = (size_t)W * H;
-  const int os = (int)aa[0];
-  const double r0 = aa[1];
-  col_t bgc = C3(bg[0], bg[1], bg[2]);
   double *maps = (double *)malloc(total * 8 * sizeof(double));
 #ifdef _OPENMP
   int nt = threads > 0 ? threads : omp_get_max_threads();
@@ -1387,25 +1384,62 @@ void orc_render_antialiasing(orc_scene *s, const orc_camera *c, const double aa[
     maps[p] = t; maps[total + p] = norm.x; maps[2 * total + p] = norm.y; maps[3 * total + p] = norm.z; maps[4 * total + p] = type;
     if (!focusing) {
       rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = 0; g.path = 1;
+      const struct orc_godray *god = tl_god; hp_sink_t *sink = tl_hp;
+      tl_god = NULL; tl_hp = NULL;                                        /* the maps come from the plain RayTracer (:116, :348, :483) */
       col_t c0 = ray_tracer(s, ray, k.depth, 1, bgc, g, NULL);           /* :116 */
+      tl_god = god; tl_hp = sink;
       maps[5 * total + p] = c0.r; maps[6 * total + p] = c0.g; maps[7 * total + p] = c0.b;
     }
   }
+  (void)H;
+  return maps;
+}
+/* the test of Camera.h:137-146 (246-251, 373-382, 504-513) */
+static int aa_edge(const double *maps, int W, int H, int v, int h, const double aa[6], int focusing)
+{
+  const size_t total = (size_t)W * H;
+  int edge = fabs(laplace_at(maps, W, H, v, h)) > aa[2] ||
+             fabs(laplace_at(maps + total, W, H, v, h)) > aa[3] ||
+             fabs(laplace_at(maps + 2 * total, W, H, v, h)) > aa[3] ||
+             fabs(laplace_at(maps + 3 * total, W, H, v, h)) > aa[3] ||
+             fabs(laplace_at(maps + 4 * total, W, H, v, h)) > aa[4];
+  if (!focusing)
+    edge = edge || fabs(laplace_at(maps + 5 * total, W, H, v, h)) > aa[5] ||
+           fabs(laplace_at(maps + 6 * total, W, H, v, h)) > aa[5] ||
+           fabs(laplace_at(maps + 7 * total, W, H, v, h)) > aa[5];
+  return edge;
+}
+/* one picture-plane-jittered ray of a masked pixel: ray index `idx` (Camera.h:152-156); returns RayTracer / RayTracingPass of it */
+static col_t aa_jittered_sample(orc_scene *s, const cam_t *k, v3 pnt, v3 cur, uint32_t p, uint32_t idx, double r0, col_t bgc, uint64_t seed)
+{
+  rng_ctx g; g.seed = seed; g.pixel = p; g.sample = idx; g.path = 0;
+  double kx = ref_random(r0, 1000, &g, 1, 0, 0);
+  double ky = ref_random(r0, 1000, &g, 1, 0, 1);
+  double kz = ref_random(r0, 1000, &g, 1, 0, 2);
+  v3 cur1 = V3(cur.x + kx, cur.y + ky, cur.z + kz);
+  ray_t ray1 = mk_ray(pnt, v_unitize(v_sub(cur1, pnt)));
+  g.path = 1;
+  return ray_tracer(s, ray1, k->depth, 1, bgc, g, NULL);
+}
+
+void orc_render_antialiasing(orc_scene *s, const orc_camera *c, const double aa[6], int focusing, double radius, int spp,
+                             const double bg[3], uint64_t seed, double *rgb, unsigned char *edge_mask, int threads)
+{
+  cam_t k = cam_init(c);
+  const int W = k.W, H = k.H;
+  const size_t total = (size_t)W * H;
+  const int os = (int)aa[0];
+  const double r0 = aa[1];
+  col_t bgc = C3(bg[0], bg[1], bg[2]);
+  double *maps = aa_maps(s, &k, focusing, bgc, seed, threads);
 #ifdef _OPENMP
+  int nt = threads > 0 ? threads : omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 16) num_threads(nt)
 #endif
   for (long long p = 0; p < (long long)total; p++) {                      /* Camera.h:134-165, 243-276 */
     int v = (int)(p / W), h = (int)(p % W);
     v3 cur = cam_cur_pt(&k, h, v);
-    int edge = fabs(laplace_at(maps, W, H, v, h)) > aa[2] ||
-               fabs(laplace_at(maps + total, W, H, v, h)) > aa[3] ||
-               fabs(laplace_at(maps + 2 * total, W, H, v, h)) > aa[3] ||
-               fabs(laplace_at(maps + 3 * total, W, H, v, h)) > aa[3] ||
-               fabs(laplace_at(maps + 4 * total, W, H, v, h)) > aa[4];
-    if (!focusing)
-      edge = edge || fabs(laplace_at(maps + 5 * total, W, H, v, h)) > aa[5] ||
-             fabs(laplace_at(maps + 6 * total, W, H, v, h)) > aa[5] ||
-             fabs(laplace_at(maps + 7 * total, W, H, v, h)) > aa[5];
+    int edge = aa_edge(maps, W, H, v, h, aa, focusing);
     if (edge_mask) edge_mask[p] = (unsigned char)edge;
     col_t colour = C3(0, 0, 0);
     const int n_lens = focusing ? spp : 1;
@@ -1420,14 +1454,7 @@ void orc_render_antialiasing(orc_scene *s, const orc_camera *c, const double aa[
       }
       if (edge) {
         for (int j = 0; j < os; j++) {                                    /* :152-157, 264-269 */
-          rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = (uint32_t)(i * os + j); g.path = 0;
-          double kx = ref_random(r0, 1000, &g, 1, 0, 0);
-          double ky = ref_random(r0, 1000, &g, 1, 0, 1);
-          double kz = ref_random(r0, 1000, &g, 1, 0, 2);
-          v3 cur1 = V3(cur.x + kx, cur.y + ky, cur.z + kz);
-          ray_t ray1 = mk_ray(pnt, v_unitize(v_sub(cur1, pnt)));
-          g.path = 1;
-          col_t sc = ray_tracer(s, ray1, k.depth, 1, bgc, g, NULL);
+          col_t sc = aa_jittered_sample(s, &k, pnt, cur, (uint32_t)p, (uint32_t)(i * os + j), r0, bgc, seed);
           colour = c_add(colour, c_div(sc, focusing ? (double)(spp * os) : (double)os));
         }
         continue;
@@ -1458,6 +1485,8 @@ struct orc_ppm {
   kd_node *root;
   unsigned char *picture;                                                 /* CV_8UC3, stored R,G,B here */
   int64_t photon_segments, photon_hits;
+  /* Render_PhotonMapper_Antialiasing (Camera.h:315-423): the passes add into a CV_32SC3 picture, `picture` is picture_ori */
+  int aa_os; unsigned char *aa_mask; int *sum32;
 };
 
 static int cmp_axis;
@@ -1529,6 +1558,10 @@ static void kd_radiance(orc_ppm *m, kd_node *node)
   hitpoint_t *hp = &node->hp;
   unsigned char *px = &m->picture[3 * ((size_t)hp->v * m->cam.W + hp->h)];
   const double t[3] = {hp->tau.r, hp->tau.g, hp->tau.b};
+  if (m->sum32) {                                                         /* :365-367: Vec3i(tau...) * wgt added to the CV_32SC3 picture */
+    int *q = &m->sum32[3 * ((size_t)hp->v * m->cam.W + hp->h)];
+    for (int c = 0; c < 3; c++) q[c] += (int)nearbyint((double)(int)t[c] * hp->wgt);     /* int truncation, then saturate_cast<int>(x * wgt) = cvRound */
+  } else
   for (int c = 0; c < 3; c++) {
     unsigned char tb = (unsigned char)t[c];                               /* Vec3b(tau...): double -> uchar truncation */
     unsigned char add = sat_u8((double)tb * hp->wgt);                     /* Vec3b * double */
@@ -1559,12 +1592,12 @@ orc_ppm *orc_ppm_begin(orc_scene *s, const orc_camera *c, const double bg[3], ui
   const size_t total = (size_t)k.W * k.H;
   m->picture = (unsigned char *)calloc(total, 3);
   col_t bgc = C3(bg[0], bg[1], bg[2]);
-  hp_sink_t all = {NULL, 0, 0, k.W};
+  hp_sink_t all = {NULL, 0, 0, k.W, 0};
 #ifdef _OPENMP
 #pragma omp parallel
 #endif
   {
-    hp_sink_t mine = {NULL, 0, 0, k.W};
+    hp_sink_t mine = {NULL, 0, 0, k.W, 0};
     tl_hp = &mine;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 64)
@@ -1595,6 +1628,70 @@ orc_ppm *orc_ppm_begin(orc_scene *s, const orc_camera *c, const double bg[3], ui
   free(tmp);
   return m;
 }
+
+/* Camera.h:315-399 Render_PhotonMapper_Antialiasing up to PhotonMappingPass: maps from the plain RayTracer, edge mask, then the eye
+ * pass -- a masked pixel sends oversampleTimes jittered rays through RayTracingPass, all of them depositing hit points on (h, v)
+ * (:384-389), the others one ray (:393-394); picture_ori = the clamped colours, truncated (:390, :395).
+ * aa[6] as in orc_render_antialiasing.  Hit-point key: (pixel, (ray index << 12) | ray-tree path). */
+orc_ppm *orc_ppm_begin_aa(orc_scene *s, const orc_camera *c, const double aa[6], const double bg[3], uint64_t seed, int photon_num, int times)
+{
+  orc_ppm *m = (orc_ppm *)calloc(1, sizeof *m);
+  m->s = s; m->cam = cam_init(c); m->seed = seed; m->photon_num = photon_num > 0 ? photon_num : 50000; m->times = times;
+  m->n_emitted = (long long)times * s->n_lights * m->photon_num;          /* :225 */
+  const cam_t k = m->cam;
+  const int W = k.W, H = k.H;
+  const size_t total = (size_t)W * H;
+  const int os = (int)aa[0];
+  m->picture = (unsigned char *)calloc(total, 3);
+  m->aa_os = os; m->aa_mask = (unsigned char *)calloc(total, 1); m->sum32 = (int *)calloc(total * 3, sizeof(int));
+  col_t bgc = C3(bg[0], bg[1], bg[2]);
+  double *maps = aa_maps(s, &k, 0, bgc, seed, 0);
+  hp_sink_t all = {NULL, 0, 0, W, 1};
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    hp_sink_t mine = {NULL, 0, 0, W, 1};
+    tl_hp = &mine;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+    for (long long p = 0; p < (long long)total; p++) {
+      int v = (int)(p / W), h = (int)(p % W);
+      v3 cur = cam_cur_pt(&k, h, v);
+      col_t colour = C3(0, 0, 0);
+      if (aa_edge(maps, W, H, v, h, aa, 0)) {
+        m->aa_mask[p] = 1;
+        for (int j = 0; j < os; j++)                                      /* :384-389 */
+          colour = c_add(colour, c_div(aa_jittered_sample(s, &k, k.view_pt, cur, (uint32_t)p, (uint32_t)j, aa[1], bgc, seed), (double)os));
+      } else {
+        ray_t ray = mk_ray(k.view_pt, v_unitize(v_sub(cur, k.view_pt)));  /* :393-394 */
+        rng_ctx g; g.seed = seed; g.pixel = (uint32_t)p; g.sample = 0; g.path = 1;
+        colour = ray_tracer(s, ray, k.depth, 1, bgc, g, NULL);
+      }
+      m->picture[3 * p] = (unsigned char)colour.r; m->picture[3 * p + 1] = (unsigned char)colour.g; m->picture[3 * p + 2] = (unsigned char)colour.b;
+    }
+    tl_hp = NULL;
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+    {
+      all.a = (hitpoint_t *)realloc(all.a, (all.n + mine.n + 1) * sizeof(hitpoint_t));
+      memcpy(all.a + all.n, mine.a, mine.n * sizeof(hitpoint_t)); all.n += mine.n;
+    }
+    free(mine.a);
+  }
+  free(maps);
+  qsort(all.a, all.n, sizeof(hitpoint_t), cmp_key);
+  m->hps = all.a; m->n_hp = all.n;
+  hitpoint_t *tmp = (hitpoint_t *)malloc((all.n + 1) * sizeof(hitpoint_t));
+  memcpy(tmp, all.a, all.n * sizeof(hitpoint_t));
+  m->root = kd_build(tmp, all.n);
+  free(tmp);
+  return m;
+}
+void orc_ppm_edge_mask(const orc_ppm *m, unsigned char *mask)
+{ const size_t n = (size_t)m->cam.W * m->cam.H; if (m->aa_mask) memcpy(mask, m->aa_mask, n); else memset(mask, 0, n); }
 
 /* one iteration of the loop of PhotonMappingPass (:226-238): GeneratePhotons, TracePhotons, AccumulatePhotons, RadianceEvaluation */
 void orc_ppm_pass(orc_ppm *m, int pass_index)
@@ -1664,9 +1761,18 @@ void orc_ppm_hitpoints(const orc_ppm *m, double *out)
   free(tmp);
 }
 void orc_ppm_picture(const orc_ppm *m, double *rgb)
-{ const size_t n = (size_t)m->cam.W * m->cam.H * 3; for (size_t i = 0; i < n; i++) rgb[i] = m->picture[i]; }
+{
+  const size_t n = (size_t)m->cam.W * m->cam.H * 3;
+  if (!m->sum32) { for (size_t i = 0; i < n; i++) rgb[i] = m->picture[i]; return; }
+  for (size_t i = 0; i < n; i++) {                                        /* Camera.h:402-420 */
+    int add = m->sum32[i];
+    if (m->aa_mask[i / 3]) add = (int)nearbyint((double)add * (1. / m->aa_os));    /* Vec3i / int = a * (1. / alpha), saturate_cast<int> */
+    int v = (int)m->picture[i] + add;                                     /* Vec3b += Vec3i: saturate_cast<uchar> */
+    rgb[i] = (double)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  }
+}
 void orc_ppm_counters(const orc_ppm *m, int64_t out[2]) { out[0] = m->photon_segments; out[1] = m->photon_hits; }
-void orc_ppm_end(orc_ppm *m) { if (!m) return; kd_free(m->root); free(m->hps); free(m->picture); free(m); }
+void orc_ppm_end(orc_ppm *m) { if (!m) return; kd_free(m->root); free(m->hps); free(m->picture); free(m->aa_mask); free(m->sum32); free(m); }
 
 
 /* ------------------------------------------------------------------ god ray (GodRay.h, Camera.h:425-448) */
@@ -1810,6 +1916,45 @@ void orc_render_godray(orc_godray *g, const orc_camera *c, const double bg[3], d
     }
     tl_god = NULL;
   }
+}
+/* Camera.h:450-537 Render_RayTracer_GodRay_Antialiasing after PhotonMappingPass: maps from the plain RayTracer (:483), masked pixels
+ * re-sampled with oversampleTimes jittered rays through CGodRay::RayTracingPass (:516-523), the others one such ray (:527-528).
+ * rgb NOT truncated. */
+void orc_render_godray_aa(orc_godray *g, const orc_camera *c, const double aa[6], const double bg[3], double *rgb, unsigned char *edge_mask)
+{
+  cam_t k = cam_init(c);
+  const int W = k.W, H = k.H;
+  const size_t total = (size_t)W * H;
+  const int os = (int)aa[0];
+  col_t bgc = C3(bg[0], bg[1], bg[2]);
+  double *maps = aa_maps(g->s, &k, 0, bgc, g->seed, 0);
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    tl_god = g;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+    for (long long p = 0; p < (long long)total; p++) {
+      int v = (int)(p / W), h = (int)(p % W);
+      v3 cur = cam_cur_pt(&k, h, v);
+      col_t colour = C3(0, 0, 0);
+      int edge = aa_edge(maps, W, H, v, h, aa, 0);
+      if (edge_mask) edge_mask[p] = (unsigned char)edge;
+      if (edge) {
+        for (int j = 0; j < os; j++)
+          colour = c_add(colour, c_div(aa_jittered_sample(g->s, &k, k.view_pt, cur, (uint32_t)p, (uint32_t)j, aa[1], bgc, g->seed), (double)os));
+      } else {
+        ray_t ray = mk_ray(k.view_pt, v_unitize(v_sub(cur, k.view_pt)));
+        rng_ctx rg; rg.seed = g->seed; rg.pixel = (uint32_t)p; rg.sample = 0; rg.path = 1;
+        colour = ray_tracer(g->s, ray, k.depth, 1, bgc, rg, NULL);
+      }
+      rgb[3 * p] = colour.r; rgb[3 * p + 1] = colour.g; rgb[3 * p + 2] = colour.b;
+    }
+    tl_god = NULL;
+  }
+  free(maps);
 }
 void orc_godray_free(orc_godray *g) { if (!g) return; god_free(g->root); free(g->src); free(g->ph); free(g); }
 

@@ -127,6 +127,9 @@ void orc_render_antialiasing(orc_scene *s, const orc_camera *c, const double aa[
  * rand() is replaced by the counter generator keyed (seed, pass, photon index, draw number). */
 typedef struct orc_ppm orc_ppm;
 orc_ppm *orc_ppm_begin(orc_scene *s, const orc_camera *c, const double bg[3], uint64_t seed, int photon_num, int times);
+/* CCamera::Render_PhotonMapper_Antialiasing (Camera.h:315-423) up to PhotonMappingPass; aa[6] as in orc_render_antialiasing */
+orc_ppm *orc_ppm_begin_aa(orc_scene *s, const orc_camera *c, const double aa[6], const double bg[3], uint64_t seed, int photon_num, int times);
+void orc_ppm_edge_mask(const orc_ppm *m, unsigned char *mask);
 void orc_ppm_pass(orc_ppm *m, int pass_index);
 size_t orc_ppm_num_hitpoints(const orc_ppm *m);
 /* sorted by (pixel, ray-tree path); 14 doubles each: pixel, path, pt[3], norm[3], wgt, R, N, tau[3] */
@@ -144,6 +147,8 @@ void orc_godray_build(orc_godray *g);
 size_t orc_godray_num_photons(const orc_godray *g);
 void orc_godray_photons(const orc_godray *g, double *out /* 4 per photon: x, y, z, energy; creation order */);
 void orc_render_godray(orc_godray *g, const orc_camera *c, const double bg[3], double *rgb, int32_t *prim_id);
+/* CCamera::Render_RayTracer_GodRay_Antialiasing (Camera.h:450-537) after PhotonMappingPass */
+void orc_render_godray_aa(orc_godray *g, const orc_camera *c, const double aa[6], const double bg[3], double *rgb, unsigned char *edge_mask);
 void orc_godray_free(orc_godray *g);
 
 /* single primitive known-answer helper: hit point of object id for one ray (recorded variant) */

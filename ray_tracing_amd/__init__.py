@@ -177,6 +177,10 @@ hip.rt_hip_godray_photons.argtypes = [_vp, _vp]
 hip.rt_hip_render_godray.argtypes = [_vp, _vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
 hip.rt_hip_render_godray_dev.argtypes = [_vp, _vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_godray_destroy.argtypes = [_vp]
+hip.rt_hip_ppm_begin_aa.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.POINTER(AaParams), C.c_uint32, C.c_uint32, C.POINTER(_vp)]
+hip.rt_hip_ppm_edge_mask.argtypes = [_vp, _vp]
+hip.rt_hip_render_godray_antialiasing.argtypes = [_vp, _vp, C.POINTER(CameraStruct), C.POINTER(Params), C.POINTER(AaParams), _vp, _vp]
+hip.rt_hip_render_godray_antialiasing_dev.argtypes = [_vp, _vp, C.POINTER(CameraStruct), C.POINTER(Params), C.POINTER(AaParams), _vp, _vp, _vp]
 hip.rt_hip_ppm_begin.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), C.c_uint32, C.c_uint32, C.POINTER(_vp)]
 hip.rt_hip_ppm_info.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 hip.rt_hip_ppm_trace.argtypes = [_vp, C.c_uint32, C.c_uint64, C.c_uint64, _vp]
@@ -280,6 +284,15 @@ class GodRay:
         check(hip.rt_hip_render_godray(self._scene.device(self._ctx), self.raw, camera.raw, p, rgb.ctypes.data, ids.ctypes.data))
         return rgb, ids
 
+    def render_antialiasing(self, camera, aa=None, background=(0, 0, 0)):
+        """CCamera::Render_RayTracer_GodRay_Antialiasing: (rgb (n,3) doubles, edge mask (n,) uint8)"""
+        n = camera.width * camera.height
+        rgb = np.zeros((n, 3)); mask = np.zeros(n, np.uint8)
+        p = Params(background=background, seed=self.seed)
+        check(hip.rt_hip_render_godray_antialiasing(self._scene.device(self._ctx), self.raw, camera.raw, p, aa if aa is not None else AaParams(),
+                                                    rgb.ctypes.data, mask.ctypes.data))
+        return rgb, mask
+
     def __del__(self):
         if getattr(self, "raw", None) and hip is not None:
             hip.rt_hip_godray_destroy(self.raw)
@@ -289,12 +302,21 @@ class GodRay:
 class PhotonMap:
     """CPhotonMapper driven as in CCamera::Render_PhotonMapper (Camera.h:291-313) through rt_hip_ppm_*"""
 
-    def __init__(self, ctx, scene, camera, photon_num=50000, times=1, background=(0, 0, 0), seed=0):
+    def __init__(self, ctx, scene, camera, photon_num=50000, times=1, background=(0, 0, 0), seed=0, aa=None):
+        """aa = AaParams: CCamera::Render_PhotonMapper_Antialiasing (Camera.h:315-423) through rt_hip_ppm_begin_aa"""
         self._scene, self._ctx, self._cam = scene, ctx, camera
         self.raw = _vp()
         p = Params(background=background, seed=seed)
-        check(hip.rt_hip_ppm_begin(scene.device(ctx), camera.raw, p, photon_num, times, C.byref(self.raw)))
+        if aa is None:
+            check(hip.rt_hip_ppm_begin(scene.device(ctx), camera.raw, p, photon_num, times, C.byref(self.raw)))
+        else:
+            check(hip.rt_hip_ppm_begin_aa(scene.device(ctx), camera.raw, p, aa, photon_num, times, C.byref(self.raw)))
         self.width, self.height = camera.width, camera.height
+
+    def edge_mask(self):
+        out = np.zeros(self.width * self.height, dtype=np.uint8)
+        check(hip.rt_hip_ppm_edge_mask(self.raw, out.ctypes.data))
+        return out
 
     def info(self):
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()

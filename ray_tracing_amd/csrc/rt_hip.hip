@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <atomic>
 #include <memory>
@@ -102,7 +103,7 @@ struct rt_hip_scene {
   bool keep_uv = false;            // photon mapping eye pass: keep the (u, v) of every node's hit (k_shade overwrites them)
   bool one_sample = false;         // exactly one light and it takes one shadow ray per point: k_frame_direct has a loop-free form for it
   DevBuf uv[kMaxLevels];
-  DevBuf aa_maps, aa_edges;        // anti-aliasing drivers: G-buffer maps, list of masked pixels
+  DevBuf aa_maps, aa_edges, aa_mask;   // anti-aliasing drivers: G-buffer maps, list of masked pixels, the mask when the caller keeps none
   uint64_t last_aa_edges = 0;
   // optional per-kernel timing (rt_hip_set_profiling)
   bool prof_on = false;
@@ -1130,7 +1131,7 @@ extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
   for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &b : s->levels) b.release();
   for (auto &b : s->uv) b.release();
-  s->counter.release(); s->staging.release(); s->lum.release(); s->order.release(); s->aa_maps.release(); s->aa_edges.release();
+  s->counter.release(); s->staging.release(); s->lum.release(); s->order.release(); s->aa_maps.release(); s->aa_edges.release(); s->aa_mask.release();
   ctx_release(s->ctx);
   delete s;
   return RT_HIP_OK;

@@ -590,10 +590,36 @@ class Camera {                   // CCamera, Camera.h:14-51
   // rewritten with the picture after every pass (the reference shows the picture once, at the end, Camera.h:310-312).
   void Render_PhotonMapper(Context &ctx, Scene &scene, int times, Colour background = Colour(0, 0, 0), uint32_t photonNum = 50000,
                            const std::string &checkpoint = "", const std::string &progress = "")
+  { photon_mapper(ctx, scene, times, background, photonNum, checkpoint, progress, 0); }
+  // Render_PhotonMapper_Antialiasing, Camera.h:315-423 (what Layout5_Wine calls, Layout.h:299): the edge mask of
+  // Render_RayTracer_Antialiasing, oversampleTimes jittered eye rays per masked pixel all depositing hit points on it, the photon
+  // sums of a masked pixel divided by oversampleTimes.  edge_mask(): 1 where a pixel was re-sampled.
+  void Render_PhotonMapper_Antialiasing(Context &ctx, Scene &scene, int times, Colour background = Colour(0, 0, 0), uint32_t photonNum = 50000,
+                                        uint32_t oversampleTimes = 100, const std::string &checkpoint = "", const std::string &progress = "")
+  { photon_mapper(ctx, scene, times, background, photonNum, checkpoint, progress, oversampleTimes ? oversampleTimes : 100); }
+  // Render_RayTracer_GodRay_Antialiasing, Camera.h:450-537 (what Layout6_Room calls, Layout.h:321)
+  void Render_RayTracer_GodRay_Antialiasing(GodRay &godRay, Colour background = Colour(0, 0, 0), uint32_t oversampleTimes = 100)
+  {
+    godRay.PhotonMappingPass();
+    rt_hip_params p = params(background);
+    rt_hip_aa_params a{}; a.struct_size = sizeof a; a.oversample_times = oversampleTimes;
+    rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.clear(); mask_.assign((size_t)w_ * h_, 0);
+    check(rt_hip_render_godray_antialiasing(godRay.scene(), godRay.get(), &cam_, &p, &a, rgb_.data(), mask_.data()), "rt_hip_render_godray_antialiasing");
+    to_picture();
+  }
+ private:
+  void photon_mapper(Context &ctx, Scene &scene, int times, Colour background, uint32_t photonNum, const std::string &checkpoint,
+                     const std::string &progress, uint32_t oversampleTimes)
   {
     rt_hip_params p = params(background);
     rt_hip_ppm *m = nullptr;
-    check(rt_hip_ppm_begin(scene.Device(ctx), &cam_, &p, photonNum, (uint32_t)times, &m), "rt_hip_ppm_begin");
+    if (oversampleTimes) {
+      rt_hip_aa_params a{}; a.struct_size = sizeof a; a.oversample_times = oversampleTimes;
+      check(rt_hip_ppm_begin_aa(scene.Device(ctx), &cam_, &p, &a, photonNum, (uint32_t)times, &m), "rt_hip_ppm_begin_aa");
+      mask_.assign((size_t)w_ * h_, 0);
+      check(rt_hip_ppm_edge_mask(m, mask_.data()), "rt_hip_ppm_edge_mask");
+    } else
+      check(rt_hip_ppm_begin(scene.Device(ctx), &cam_, &p, photonNum, (uint32_t)times, &m), "rt_hip_ppm_begin");
     int rc = 0;
     uint32_t first = 0;
     std::vector<unsigned char> state;
@@ -625,6 +651,7 @@ class Camera {                   // CCamera, Camera.h:14-51
     check(rc, "rt_hip_ppm_pass");
     to_picture();
   }
+ public:
   // Render_RayTracer_GodRay, Camera.h:425-448 (the caller runs godRay.PhotonMappingPass() first; the reference does it here)
   void Render_RayTracer_GodRay(GodRay &godRay, Colour background = Colour(0, 0, 0))
   {

@@ -62,6 +62,10 @@ L.orc_render_godray.argtypes = [_vp, C.POINTER(OrcCamera), d3, _vp, _vp]
 L.orc_godray_free.argtypes = [_vp]
 L.orc_ppm_begin.argtypes = [_vp, C.POINTER(OrcCamera), d3, C.c_uint64, C.c_int, C.c_int]
 L.orc_ppm_begin.restype = _vp
+L.orc_ppm_begin_aa.argtypes = [_vp, C.POINTER(OrcCamera), C.c_double * 6, d3, C.c_uint64, C.c_int, C.c_int]
+L.orc_ppm_begin_aa.restype = _vp
+L.orc_ppm_edge_mask.argtypes = [_vp, _vp]
+L.orc_render_godray_aa.argtypes = [_vp, C.POINTER(OrcCamera), C.c_double * 6, d3, _vp, _vp]
 L.orc_ppm_pass.argtypes = [_vp, C.c_int]
 L.orc_ppm_num_hitpoints.argtypes = [_vp]
 L.orc_ppm_num_hitpoints.restype = C.c_size_t
@@ -242,12 +246,22 @@ class OracleScene:
 class OraclePhotonMap:
     """orc_ppm_*: Camera.h:291-313 + PhotonMapper.h on the CPU"""
 
-    def __init__(self, scene, cam, photon_num=50000, times=1, background=(0, 0, 0), seed=0):
+    def __init__(self, scene, cam, photon_num=50000, times=1, background=(0, 0, 0), seed=0, aa=None):
+        """aa = dict(oversample_times, r0, thresholds): Render_PhotonMapper_Antialiasing (Camera.h:315-423)"""
         self._scene = scene
         w, h = C.c_int(), C.c_int()
         L.orc_camera_size(C.byref(cam), C.byref(w), C.byref(h))
         self.width, self.height = w.value, h.value
-        self.h = L.orc_ppm_begin(scene.h, C.byref(cam), d3(*background), seed, photon_num, times)
+        if aa is None:
+            self.h = L.orc_ppm_begin(scene.h, C.byref(cam), d3(*background), seed, photon_num, times)
+        else:
+            a6 = (C.c_double * 6)(float(aa.get("oversample_times", 100)), aa.get("r0", 0.007), *aa.get("thresholds", (0.8, 0.8, 0.5, 80.0)))
+            self.h = L.orc_ppm_begin_aa(scene.h, C.byref(cam), a6, d3(*background), seed, photon_num, times)
+
+    def edge_mask(self):
+        out = np.zeros(self.width * self.height, dtype=np.uint8)
+        L.orc_ppm_edge_mask(self.h, out.ctypes.data)
+        return out
 
     def run_pass(self, index):
         L.orc_ppm_pass(self.h, index)
@@ -302,6 +316,16 @@ class OracleGodRay:
         rgb = np.zeros((n, 3)); ids = np.zeros(n, np.int32)
         L.orc_render_godray(self.h, C.byref(cam), d3(*background), rgb.ctypes.data, ids.ctypes.data)
         return rgb, ids
+
+    def render_antialiasing(self, cam, oversample_times=100, r0=0.007, thresholds=(0.8, 0.8, 0.5, 80.0), background=(0, 0, 0)):
+        """Camera.h:450-537; returns (rgb (n,3), edge mask (n,) uint8)"""
+        w, h = C.c_int(), C.c_int()
+        L.orc_camera_size(C.byref(cam), C.byref(w), C.byref(h))
+        n = w.value * h.value
+        rgb = np.zeros((n, 3)); mask = np.zeros(n, dtype=np.uint8)
+        aa = (C.c_double * 6)(float(oversample_times), r0, *thresholds)
+        L.orc_render_godray_aa(self.h, C.byref(cam), aa, d3(*background), rgb.ctypes.data, mask.ctypes.data)
+        return rgb, mask
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -143,3 +143,69 @@ def test_no_edges_and_argument_errors(ctx):
     assert rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, rta.Params(), bad, rgb.ctypes.data, None) == -1
     huge = rta.AaParams(oversample_times=1 << 20, focusing=1)
     assert rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, rta.Params(spp=1 << 10), huge, rgb.ctypes.data, None) == -1
+
+
+def test_photon_mapper_antialiasing_parity(ctx):
+    """CCamera::Render_PhotonMapper_Antialiasing (Camera.h:315-423): same mask as the ray-traced driver; a masked pixel's
+    oversampleTimes jittered rays all deposit hit points on it; the passes add into the CV_32SC3 picture and a masked
+    pixel's sums are divided by oversampleTimes at the end"""
+    import oracle_bind as ob
+    import ray_tracing_amd as rta
+    g, o = scenes.build_icosahedron(material="plastic", light="point_area", extra_sphere=True)
+    cam_args = dict(scenes.C1_CAMERA, hor=3.2, ver=2.4, res=25, depth=3)
+    os_ = 5
+    gm = rta.PhotonMap(ctx, g, rta.Camera(**cam_args), photon_num=20000, times=2, background=(10, 10, 10), seed=6, aa=rta.AaParams(oversample_times=os_))
+    om = ob.OraclePhotonMap(o, scenes.oracle_camera(cam_args), photon_num=20000, times=2, background=(10, 10, 10), seed=6, aa=dict(oversample_times=os_))
+    mg, mo = gm.edge_mask(), om.edge_mask()
+    assert mo.sum() >= 200 and (mo == 0).sum() >= 200 and (mg != mo).mean() <= 1e-3
+    gh, oh = gm.hitpoints(), om.hitpoints()
+    print("ppm aa: %d masked pixels of %d, hit points %d vs %d" % (int(mo.sum()), mo.size, len(gh), len(oh)))
+    assert len(gh) == len(oh) and (gh[:, :2] == oh[:, :2]).all()                 # same (pixel, (ray << 12) | path) keys
+    assert (np.bincount(oh[:, 0].astype(np.int64), minlength=mo.size)[mo == 1] > 1).mean() > 0.5      # masked pixels hold several rays' hit points
+    assert np.abs(gh[:, 2:9] - oh[:, 2:9]).max() < 1e-6
+    d0 = np.abs(gm.picture() - om.picture()).max(axis=1)
+    assert (d0 > 1).mean() <= 1e-3                                              # picture_ori: truncation of colours that agree to ~1e-13
+    for t in range(2):
+        gm.run_pass(t); om.run_pass(t)
+        gh, oh = gm.hitpoints(), om.hitpoints()
+        dN = np.abs(gh[:, 10] - oh[:, 10])
+        print("ppm aa pass %d: N total %.1f vs %.1f, hit points with different N %d" % (t, gh[:, 10].sum(), oh[:, 10].sum(), int((dN > 1e-9).sum())))
+        assert (dN > 1e-9).mean() < 1e-3
+    pg, po = gm.picture(), om.picture()
+    d = np.abs(pg - po).max(axis=1)
+    print("ppm aa: picture max |diff| %d, pixels differing %d of %d; masked pixels brighter than the eye pass: %d" % (
+        d.max(), int((d > 0).sum()), d.size, int(((po.sum(axis=1) > 0) & (mo == 1)).sum())))
+    assert (d > 2).mean() <= 1e-3 and (d > 0).mean() < 1e-2
+    info, oc = gm.info(), om.counters()
+    assert abs(info["photon_hits"] - oc["photon_hits"]) <= 1e-4 * oc["photon_hits"]
+    # the plain driver on the same scene has one ray per pixel: fewer hit points
+    plain = rta.PhotonMap(ctx, g, rta.Camera(**cam_args), photon_num=100, times=1, background=(10, 10, 10), seed=6)
+    assert plain.info()["hitpoints"] < gm.info()["hitpoints"] and plain.edge_mask().sum() == 0
+
+
+def test_godray_antialiasing_parity(ctx):
+    """CCamera::Render_RayTracer_GodRay_Antialiasing (Camera.h:450-537): mask from the plain RayTracer's maps, every ray of
+    the final picture through CGodRay::RayTracingPass"""
+    import oracle_bind as ob
+    import ray_tracing_amd as rta
+    g, o = scenes.build_room()
+    gg = rta.GodRay(ctx, g, (155, 155, 50), seed=9)
+    og = ob.OracleGodRay(o, (155, 155, 50), seed=9)
+    for x in (gg, og):
+        x.add_area_light_source_xz(6.0, (-3.0, 0.0), (9.0, 10.0), 0.4, (1.0, -2.0, -1.0))
+        x.photon_mapping_pass()
+    cam_args = dict(scenes.ROOM_CAMERA, res=16, depth=2)
+    rgb, mask = gg.render_antialiasing(rta.Camera(**cam_args), aa=rta.AaParams(oversample_times=6), background=(20, 20, 30))
+    rgb_ref, mask_ref = og.render_antialiasing(scenes.oracle_camera(cam_args), oversample_times=6, background=(20, 20, 30))
+    agree = mask == mask_ref
+    err = _rel_err(rgb, rgb_ref)[agree]
+    print("godray aa: %d masked pixels of %d, mask mismatches %d, max rel err %.3g" % (int(mask_ref.sum()), mask.size, int((~agree).sum()), err.max()))
+    assert mask_ref.sum() >= 100 and (mask_ref == 0).sum() >= 100 and (~agree).mean() <= 1e-3
+    assert err.max() < 1e-3
+    # unmasked pixels are the plain god-ray frame; the light shafts are in it (it differs from the shaft-less render)
+    plain, _ = gg.render(rta.Camera(**cam_args), background=(20, 20, 30))
+    keep = mask == 0
+    assert (rgb[keep] == plain[keep]).all()
+    cam = rta.Camera(**cam_args); cam.set_seed(9)
+    cam.render_raytracer(ctx, g, background=(20, 20, 30))
+    assert np.abs(plain - cam.rgb()).max() > 1.0

@@ -48,3 +48,31 @@ def test_layout1_apples_program(ctx, tmp_path):
     assert subprocess.run([BIN], capture_output=True).returncode == 2
     bad = subprocess.run([BIN, "focusing", "/nonexistent.obj", out], capture_output=True, text=True)
     assert bad.returncode == 1 and "cannot open" in bad.stderr
+
+
+def test_layout5_wine_program(ctx, tmp_path):
+    """Layout5_Wine as the reference writes it (three cups, 5x5 area light, Render_PhotonMapper_Antialiasing) through the C++ host
+    mirror; compared with the same run driven through the ctypes harness"""
+    import ray_tracing_amd as rta
+    out = str(tmp_path / "wine.ppm")
+    r = subprocess.run([BIN, "wine", out, "8", "2", "600", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = _read_ppm(out)
+    assert "24 objects" in r.stdout
+    g, _ = scenes.build_wine(cups="layout", light="area5", oracle=False)
+    cam = rta.Camera(view=(-23.5, 27.5, 24), eye=(2.9, -3, -2), left=(-1, -1, 0), dist=15, hor=8, ver=6, res=8, depth=8)
+    pm = rta.PhotonMap(ctx, g, cam, photon_num=600, times=2, background=(0, 0, 0), seed=1, aa=rta.AaParams(oversample_times=3))
+    for t in range(2):
+        pm.run_pass(t)
+    pic = pm.picture().reshape(cam.height, cam.width, 3)
+    assert img.shape == pic.shape and int(r.stdout.split(",")[2].split()[0]) == int(pm.edge_mask().sum()) > 50
+    assert (img == pic.astype(np.uint8)).all()
+
+
+def test_layout6_room_program(ctx, tmp_path):
+    out = str(tmp_path / "room.ppm")
+    r = subprocess.run([BIN, "room", scenes.ICOSA_OBJ, out, "10", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    img = _read_ppm(out)
+    assert img.shape == (60, 80, 3) and img.std() > 10
+    assert int(r.stdout.split(",")[1].split()[0]) > 100
