@@ -99,7 +99,9 @@ struct rt_hip_scene {
   DevBuf staging;                 // host-pointer entry points
   uint64_t last_rays = 0, last_shadow = 0;
   const void *last_counters = nullptr;   // RenderCounters of the last render call (the scene's own, or the allocation-free entry point's)
-  unsigned int last_n_level[kMaxLevels] = {0}; int last_level = 0;   // sizes of the level arrays of the last run
+  unsigned int last_n_level[kMaxLevels] = {0}; int last_level = 0;   // sizes of the level arrays of the last run: bounds until level_counts() settles them
+  bool last_exact[kMaxLevels] = {false};
+  unsigned int fan = 2;            // children a ray-tree node can have: 2 when some material both reflects and refracts, else 1
   bool keep_uv = false;            // photon mapping eye pass: keep the (u, v) of every node's hit (k_shade overwrites them)
   bool one_sample = false;         // exactly one light and it takes one shadow ray per point: k_frame_direct has a loop-free form for it
   DevBuf uv[kMaxLevels];
@@ -114,7 +116,12 @@ struct rt_hip_scene {
   uint32_t n_nodes = 0, n_leaves = 0, n_cull = 0, max_depth = 0;
 };
 
-struct RenderCounters { unsigned int queue_count; unsigned int pad; unsigned long long rays; unsigned long long shadow_rays; };
+// level_n[lv]: nodes of ray-tree level lv of the render in flight, counted on the device (k_shade appends level lv + 1) so that the host
+// never waits for a level to learn the size of the next
+struct RenderCounters { unsigned int queue_count; unsigned int pad; unsigned long long rays; unsigned long long shadow_rays; unsigned int level_n[16]; };
+// number of nodes a level kernel works on: the host's bound (cap), cut to the device's count when one is given
+__device__ __forceinline__ unsigned int level_count(const unsigned int *n_dev, unsigned int cap)
+{ if (!n_dev) return cap; const unsigned int n = *n_dev; return n < cap ? n : cap; }
 
 // ================================================================================================
 // scene preparation (host)
@@ -841,10 +848,12 @@ __device__ __forceinline__ uint64_t node_of_pixel(const RenderArgs &A, uint64_t 
 
 // levels >= 1: closest hit for queued secondary rays
 template <bool STATS, bool PARAM>
-__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n, Stats *gstats)
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_trace_nodes(DevScene sc, PathNode *nodes, unsigned int n_cap, const unsigned int *n_dev, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
+  const unsigned int n = level_count(n_dev, n_cap);
+  if (blockIdx.x * RT_BLOCK >= n) return;                     // the grid is sized for the bound: blocks beyond the level's real size leave at once
   const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
   const bool active = i < n;
   Stats st{};
@@ -860,12 +869,14 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
 // Shadow pass: luminosity of every light at every hit node (Scene.h:104-109), one wave-packet
 // occlusion walk per light sample.  Kept apart from k_shade so that the walk runs at full occupancy.
 template <bool STATS, bool PARAM>
-__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n, double *lum,
+__global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_shadow(DevScene sc, RenderArgs A, const PathNode *nodes, unsigned int n_cap, const unsigned int *n_dev, double *lum,
                                                       const unsigned int *order, RenderCounters *cnt, Stats *gstats)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
-  const unsigned int slot = xcd_remap(blockIdx.x, gridDim.x) * RT_WAVES + (threadIdx.x >> 6);
+  const unsigned int n = level_count(n_dev, n_cap);
+  if (!order && blockIdx.x * RT_BLOCK >= n) return;           // (with an order list -- level 0 only -- n is the host's exact count)
+  const unsigned int slot = (order ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x) * RT_WAVES + (threadIdx.x >> 6);
   const unsigned int i = (order ? (unsigned int)uni((int)order[slot]) : slot) * 64 + (threadIdx.x & 63);
   const bool in_range = i < n;
   Stats st{};
@@ -901,10 +912,12 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
 // direct_rgb != NULL (level 0 of a depth-1 frame, one sample per pixel): the colour is final, so it goes straight
 // to the frame (Camera.h:69) and the separate resolve pass over the level array is skipped.
 template <bool PARAM>
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, PathNode *nodes, unsigned int n, int depth_left,
-                                                     const double *lum, PathNode *next, unsigned int next_cap, RenderCounters *cnt,
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, PathNode *nodes, unsigned int n_cap, const unsigned int *n_dev, int depth_left,
+                                                     const double *lum, PathNode *next, unsigned int next_cap, RenderCounters *cnt, int next_level,
                                                      double *direct_rgb, int32_t *direct_id, double *uv_out)
 {
+  const unsigned int n = level_count(n_dev, n_cap);
+  if (blockIdx.x * RT_BLOCK >= n) return;
   const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
   const bool in_range = i < n;
   PathNode nd;
@@ -946,7 +959,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, P
   const unsigned int total = __popcll(m1) + __popcll(m2);
   unsigned int base = 0;
   if (total) {
-    if (lane == 0) base = atomicAdd(&cnt->queue_count, total);
+    if (lane == 0) { base = atomicAdd(&cnt->level_n[next_level], total); atomicAdd(&cnt->rays, (unsigned long long)total); }   // census: every child is one closest-hit query
     base = __builtin_amdgcn_readfirstlane(base);
   }
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -986,10 +999,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(DevScene sc, RenderArgs A, P
 }
 
 // bottom-up composition with the reference's clamped colour arithmetic (RayTracer.h:33, 45, 50)
-__global__ void __launch_bounds__(RT_BLOCK) k_combine(PathNode *nodes, unsigned int n, const PathNode *next, RenderArgs A)
+__global__ void __launch_bounds__(RT_BLOCK) k_combine(PathNode *nodes, unsigned int n_cap, const unsigned int *n_dev, const PathNode *next, RenderArgs A)
 {
   const unsigned int i = blockIdx.x * RT_BLOCK + threadIdx.x;
-  if (i >= n) return;
+  if (i >= level_count(n_dev, n_cap)) return;
   PathNode &w = nodes[i];
   Col c = mkc(w.col[0], w.col[1], w.col[2]);
   const Col bg = mkc(A.bg[0], A.bg[1], A.bg[2]);
@@ -1265,6 +1278,8 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
     o.type = L.type; o.sample_num = L.sample_num; std::memcpy(o.p, L.pos_or_dir, 24); o.lum = L.luminosity; o.len = L.len;
     o.lum_per_sample = (L.type == RT_HIP_AREA_LIGHT) ? L.luminosity / (L.sample_num * L.sample_num) : 0.0;   // Light.h:107
   }
+  s->fan = 1;
+  for (uint32_t k = 0; k < d->n_materials; k++) if (d->materials[k].reflW != 0 && d->materials[k].refrW != 0) s->fan = 2;
   s->one_sample = d->n_lights == 1 && (d->lights[0].type != RT_HIP_AREA_LIGHT || d->lights[0].sample_num == 1);
   std::vector<uint8_t> types(d->obj_type, d->obj_type + d->n_objects);
   std::vector<uint32_t> index(d->obj_index, d->obj_index + d->n_objects), omat(d->obj_material, d->obj_material + d->n_objects);
@@ -1325,7 +1340,7 @@ extern "C" int rt_hip_scene_share(rt_hip_scene *src, rt_hip_scene **out)
   rt_hip_scene *s = new rt_hip_scene();
   s->ctx = src->ctx; ctx_retain(s->ctx); s->dev = src->dev; s->geo = src->geo;
   s->n_nodes = src->n_nodes; s->n_leaves = src->n_leaves; s->n_cull = src->n_cull; s->max_depth = src->max_depth;
-  s->one_sample = src->one_sample;
+  s->one_sample = src->one_sample; s->fan = src->fan;
   *out = s;
   return RT_HIP_OK;
 }
@@ -1469,7 +1484,7 @@ extern "C" int rt_hip_camera_size(const rt_hip_camera *cam, int *w, int *h)
   return RT_HIP_OK;
 }
 
-static int godray_level(rt_hip_scene *s, PathNode *nodes, unsigned int n, hipStream_t st);   // rt_godray.inc
+static int godray_level(rt_hip_scene *s, PathNode *nodes, unsigned int n, const unsigned int *n_dev, hipStream_t st);   // rt_godray.inc
 
 // Levels of the ray tree once level 0 holds its n0 nodes with their closest hits (k_primary / k_primary_list):
 // shadow pass, shading + child rays, closest hit of the children, ... and the bottom-up composition.
@@ -1481,28 +1496,46 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
   RenderCounters *cnt = (RenderCounters *)s->counter.p;
   Stats *gs = stats ? s->ctx->d_stats : nullptr;
   const bool param = s->dev.has_param != 0;
-  unsigned int n_level[rt_hip_scene::kMaxLevels] = {0};
-  n_level[0] = (unsigned int)n0;
+  // cap[lv]: the host's bound on the size of level lv.  Level 0 is exact.  Below it the sizes are only known on the device
+  // (cnt->level_n): level lv + 1 holds at most `fan` children per node of level lv (2 when some material both reflects and
+  // refracts, else 1), the kernels are launched for that bound and their surplus blocks leave at once -- no read-back, no
+  // wait per level.  Only when the bound would outgrow kLevelBudget (deep trees through glass at full resolution) the real
+  // size of that level is fetched, as every level's was before.
+  unsigned int cap[rt_hip_scene::kMaxLevels] = {0};
+  bool exact[rt_hip_scene::kMaxLevels] = {false};
+  cap[0] = (unsigned int)n0; exact[0] = true;
+  constexpr uint64_t kLevelBudget = 6ull << 30;
   int depth = A.cam.depth < 1 ? 1 : A.cam.depth;
   if (depth > rt_hip_scene::kMaxLevels) return fail(RT_HIP_EUNSUPPORTED, "camera depth > 12: the sampler keys 12 bits of ray-tree path (rng_counter), deeper rays would share random streams");
+  HIP_TRY(hipMemsetAsync(cnt->level_n, 0, sizeof cnt->level_n, st));
   int last = 0;
   for (int lv = 0; lv < depth; lv++) {
-    const unsigned int n = n_level[lv];
+    const unsigned int n = cap[lv];
     if (n == 0) break;
     last = lv;
+    const unsigned int *n_dev = exact[lv] ? nullptr : &cnt->level_n[lv];
     const int depth_left = depth - lv;
     unsigned int next_cap = 0; PathNode *next = nullptr;
+    bool fetch_next = false;
     if (depth_left > 1) {
-      uint64_t cap = 2ull * n;
-      if (cap > 0x7FFFFFFFull) return fail(RT_HIP_ENOMEM, "ray tree level too large");
-      rc = s->levels[lv + 1].ensure(cap * sizeof(PathNode)); if (rc) return rc;
-      next = (PathNode *)s->levels[lv + 1].p; next_cap = (unsigned int)cap;
+      uint64_t bound = (uint64_t)s->fan * n;
+      if (bound * sizeof(PathNode) > kLevelBudget) { bound = 2ull * n; fetch_next = true; }   // too large to run blind: learn the real size after this level
+      if (bound > 0x7FFFFFFFull) return fail(RT_HIP_ENOMEM, "ray tree level too large");
+      if (fetch_next && !exact[lv]) {
+        // this level's own size is still a bound: settle it first so that the next level's array is sized from the real count
+        unsigned int real = 0;
+        HIP_TRY(hipMemcpyAsync(&real, &cnt->level_n[lv], sizeof real, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        cap[lv] = std::min(real, cap[lv]); exact[lv] = true;
+        lv--; continue;
+      }
+      rc = s->levels[lv + 1].ensure(bound * sizeof(PathNode)); if (rc) return rc;
+      next = (PathNode *)s->levels[lv + 1].p; next_cap = (unsigned int)bound;
     }
-    HIP_TRY(hipMemsetAsync(&cnt->queue_count, 0, sizeof(unsigned int), st));
     PathNode *cur = (PathNode *)s->levels[lv].p;
     if (lv > 0) {
       ProfScope ps(s, RT_HIP_K_TRACE_NODES, st);
-      RT_LAUNCH_SP(k_trace_nodes, stats, param, dim3(blocks_for(n)), st, s->dev, cur, n, gs);
+      RT_LAUNCH_SP(k_trace_nodes, stats, param, dim3(blocks_for(n)), st, s->dev, cur, n, n_dev, gs);
     }
     rc = s->lum.ensure((size_t)n * std::max(1, s->dev.n_lights) * sizeof(double)); if (rc) return rc;
     double *lum = (double *)s->lum.p;
@@ -1510,36 +1543,58 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
     if (s->dev.n_lights > 0) {
       ProfScope ps(s, RT_HIP_K_SHADOW, st);
       const unsigned int *ord = (lv == 0) ? (const unsigned int *)order1 : nullptr;
-      RT_LAUNCH_SP(k_shadow, stats, param, dim3(blocks_for(n)), st, s->dev, A, (const PathNode *)cur, n, lum, ord, cnt, gs);
+      RT_LAUNCH_SP(k_shadow, stats, param, dim3(blocks_for(n)), st, s->dev, A, (const PathNode *)cur, n, n_dev, lum, ord, cnt, gs);
     }
     {
       ProfScope ps(s, RT_HIP_K_SHADE, st);
       double *uv_out = nullptr;
       if (s->keep_uv && param) { rc = s->uv[lv].ensure((size_t)n * 16); if (rc) return rc; uv_out = (double *)s->uv[lv].p; }
-      if (param) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt,
+      const int next_level = (lv + 1 < rt_hip_scene::kMaxLevels) ? lv + 1 : lv;
+      if (param) hipLaunchKernelGGL(k_shade<true>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, n_dev, depth_left, (const double *)lum, next, next_cap, cnt, next_level,
                                     direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr, uv_out);
-      else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, depth_left, (const double *)lum, next, next_cap, cnt,
+      else hipLaunchKernelGGL(k_shade<false>, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, st, s->dev, A, cur, n, n_dev, depth_left, (const double *)lum, next, next_cap, cnt, next_level,
                               direct ? direct_rgb : (double *)nullptr, direct ? direct_id : (int32_t *)nullptr, (double *)nullptr);
     }
-    if (s->god) { rc = godray_level(s, cur, n, st); if (rc) return rc; }
+    if (s->god) { rc = godray_level(s, cur, n, n_dev, st); if (rc) return rc; }
     HIP_TRY(hipGetLastError());
     if (depth_left > 1) {
-      unsigned int qn = 0;
-      HIP_TRY(hipMemcpyAsync(&qn, &cnt->queue_count, sizeof qn, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      n_level[lv + 1] = std::min(qn, next_cap);
+      cap[lv + 1] = next_cap;
+      if (fetch_next) {
+        unsigned int qn = 0;
+        HIP_TRY(hipMemcpyAsync(&qn, &cnt->level_n[lv + 1], sizeof qn, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        cap[lv + 1] = std::min(qn, next_cap); exact[lv + 1] = true;
+      }
     }
   }
   for (int lv = last - 1; lv >= 0; lv--) {
     ProfScope ps(s, RT_HIP_K_COMBINE, st);
-    hipLaunchKernelGGL(k_combine, dim3(blocks_for(n_level[lv])), dim3(RT_BLOCK), 0, st, (PathNode *)s->levels[lv].p, n_level[lv],
+    hipLaunchKernelGGL(k_combine, dim3(blocks_for(cap[lv])), dim3(RT_BLOCK), 0, st, (PathNode *)s->levels[lv].p, cap[lv], exact[lv] ? (const unsigned int *)nullptr : &cnt->level_n[lv],
                        (const PathNode *)s->levels[lv + 1].p, A);
     HIP_TRY(hipGetLastError());
   }
-  for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) s->last_n_level[lv] = (lv <= last) ? n_level[lv] : 0;
+  // what the host knows of this ray tree: bounds (exact for level 0 and for fetched levels); level_counts() settles them when somebody
+  // needs the real sizes (photon-map eye pass, ray census)
+  for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) { s->last_n_level[lv] = (lv <= last) ? cap[lv] : 0; s->last_exact[lv] = (lv <= last) ? exact[lv] : true; }
   s->last_level = last;
-  uint64_t rays = primary_rays; for (int lv = 1; lv <= last; lv++) rays += n_level[lv];
-  s->last_rays += rays;
+  s->last_rays += primary_rays;                 // the rays of the deeper levels are counted on the device (cnt->rays)
+  return RT_HIP_OK;
+}
+
+// settles s->last_n_level to the real sizes of the last ray tree (waits for the stream's work)
+static int level_counts(rt_hip_scene *s)
+{
+  bool all = true; for (int lv = 0; lv <= s->last_level; lv++) all = all && s->last_exact[lv];
+  if (all || !s->last_counters) return RT_HIP_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  RenderCounters c{};
+  HIP_TRY(hipMemcpy(&c, s->last_counters, sizeof c, hipMemcpyDeviceToHost));
+  int last = 0;
+  for (int lv = 0; lv <= s->last_level; lv++) {
+    if (!s->last_exact[lv]) { s->last_n_level[lv] = std::min(c.level_n[lv], s->last_n_level[lv]); s->last_exact[lv] = true; }
+    if (s->last_n_level[lv]) last = lv;
+  }
+  s->last_level = last;
   return RT_HIP_OK;
 }
 
@@ -1815,7 +1870,7 @@ extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *
   RenderCounters c{};
   const void *src = s->last_counters ? s->last_counters : s->counter.p;
   if (src) HIP_TRY(hipMemcpy(&c, src, sizeof c, hipMemcpyDeviceToHost));
-  if (rays) *rays = s->last_rays + c.shadow_rays;
+  if (rays) *rays = s->last_rays + c.rays + c.shadow_rays;
   if (shadow_rays) *shadow_rays = c.shadow_rays;
   return RT_HIP_OK;
 }
