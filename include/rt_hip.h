@@ -13,8 +13,11 @@
  *    throws or aborts; rt_hip_last_error() gives the text for the calling thread;
  *  - host-pointer entry points are synchronous: inputs are copied during the call and
  *    outputs are complete on return;
- *  - *_dev entry points take DEVICE pointers plus a hipStream_t (passed as void*), only
- *    enqueue work on that stream and return; the caller synchronises;
+ *  - *_dev entry points take DEVICE pointers plus a hipStream_t (passed as void*), enqueue
+ *    their work on that stream and return; the caller synchronises.  They wait for the
+ *    stream only where a size must be known on the host: the first call that needs a larger
+ *    workspace (hipMalloc), the edge count of the anti-aliasing drivers, a ray-tree level
+ *    whose bound exceeds 6 GiB (deep trees through glass at full resolution), photon-map begin;
  *  - one context = one GPU; one process per GPU is the intended multi-GPU model (the
  *    pixel / sample range arguments of the render calls are the sharding hooks; the
  *    exchange of the shards is done by the caller, e.g. RCCL all-reduce / all-gather);
@@ -219,6 +222,8 @@ int rt_hip_trace_closest_dev(rt_hip_scene *scene, const rt_hip_ray *d_rays, size
  * (any hit at all, Light.h:87-94) applies. */
 int rt_hip_trace_occluded(rt_hip_scene *scene, const rt_hip_ray *rays, const double *ref_pts, size_t n,
                           int use_tree, uint8_t *occluded);
+int rt_hip_trace_occluded_dev(rt_hip_scene *scene, const rt_hip_ray *d_rays, const double *d_ref_pts, size_t n, int use_tree,
+                              uint8_t *d_occluded, uint32_t collect_stats, void *stream);
 
 /* ---- renders --------------------------------------------------------------------- */
 /* image size of a camera: int(horRange*resolution) x int(verRange*resolution) (Camera.h:55-56) */

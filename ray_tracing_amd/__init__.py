@@ -149,6 +149,7 @@ hip.rt_hip_get_stats.argtypes = [_vp, C.POINTER(Stats), C.c_int]
 hip.rt_hip_trace_closest.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp]
 hip.rt_hip_trace_closest_dev.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp, C.c_uint32, _vp]
 hip.rt_hip_trace_occluded.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]
+hip.rt_hip_trace_occluded_dev.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, C.c_uint32, _vp]
 hip.rt_hip_camera_size.argtypes = [C.POINTER(CameraStruct), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
 hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]

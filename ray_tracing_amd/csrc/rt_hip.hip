@@ -1438,6 +1438,22 @@ extern "C" int rt_hip_trace_closest(rt_hip_scene *s, const rt_hip_ray *rays, siz
   return RT_HIP_OK;
 }
 
+extern "C" int rt_hip_trace_occluded_dev(rt_hip_scene *s, const rt_hip_ray *d_rays, const double *d_ref_pts, size_t n, int use_tree, uint8_t *d_occluded,
+                                          uint32_t collect_stats, void *stream)
+{
+  if (!s || (n && (!d_rays || !d_occluded))) return fail(RT_HIP_EINVAL, "NULL argument");
+  if (n == 0) return RT_HIP_OK;
+  if (n > 0xFFFFFFFFull * 64) return fail(RT_HIP_EINVAL, "too many rays");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  DevScene sc = s->dev; if (!use_tree) sc.has_tree = 0;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(s, RT_HIP_K_TRACE_OCCLUDED, st);
+  RT_LAUNCH_SP(k_trace_occluded, collect_stats != 0, sc.has_param != 0, dim3(blocks_for(n)), st, sc, d_rays, d_ref_pts, n, d_occluded,
+               collect_stats ? s->ctx->d_stats : (Stats *)nullptr);
+  HIP_TRY(hipGetLastError());
+  return RT_HIP_OK;
+}
+
 extern "C" int rt_hip_trace_occluded(rt_hip_scene *s, const rt_hip_ray *rays, const double *ref_pts, size_t n, int use_tree, uint8_t *occluded)
 {
   if (!s || (n && (!rays || !occluded))) return fail(RT_HIP_EINVAL, "NULL argument");
@@ -1448,11 +1464,9 @@ extern "C" int rt_hip_trace_occluded(rt_hip_scene *s, const rt_hip_ray *rays, co
   char *base = (char *)s->staging.p;
   HIP_TRY(hipMemcpy(base, rays, rb, hipMemcpyHostToDevice));
   if (ref_pts) HIP_TRY(hipMemcpy(base + rb, ref_pts, pb, hipMemcpyHostToDevice));
-  DevScene sc = s->dev; if (!use_tree) sc.has_tree = 0;
-  { ProfScope ps(s, RT_HIP_K_TRACE_OCCLUDED, nullptr);
-  RT_LAUNCH_SP(k_trace_occluded, false, sc.has_param != 0, dim3(blocks_for(n)), (hipStream_t) nullptr, sc, (const rt_hip_ray *)base,
-               ref_pts ? (const double *)(base + rb) : (const double *)nullptr, n, (uint8_t *)(base + rb + pb), (Stats *)nullptr); }
-  HIP_TRY(hipGetLastError());
+  rc = rt_hip_trace_occluded_dev(s, (const rt_hip_ray *)base, ref_pts ? (const double *)(base + rb) : (const double *)nullptr, n, use_tree,
+                                 (uint8_t *)(base + rb + pb), 0, nullptr);
+  if (rc) return rc;
   HIP_TRY(hipMemcpy(occluded, base + rb + pb, n, hipMemcpyDeviceToHost));
   return RT_HIP_OK;
 }

@@ -164,3 +164,27 @@ def test_statistics_kernels_give_the_same_frame(ctx, scene_kind):
         assert (st["rays"] > 0) == bool(stats)
         outs.append(rgb.cpu().numpy())
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_trace_occluded_dev_matches_host_entry(ctx):
+    """rt_hip_trace_occluded_dev (device pointers, a stream, optional statistics) against the host-pointer entry point"""
+    import torch
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(extra_sphere=True, oracle=False)
+    rng = np.random.default_rng(3)
+    n = 5000
+    org = rng.uniform(-2, 2, (n, 3)) + np.array([0, -1, 2.2])
+    light = np.array([-10.0, 20.0, 20.0])
+    rays = np.ascontiguousarray(np.concatenate([org, light - org], axis=1))
+    ref = np.ascontiguousarray(np.broadcast_to(light, (n, 3)))
+    want = g.occluded(ctx, rays, ref)
+    d_rays, d_ref = torch.from_numpy(rays).cuda(), torch.from_numpy(ref).cuda()
+    d_occ = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.Stream()
+    for stats in (0, 1):
+        ctx.stats(reset=True)
+        rta.check(rta.hip.rt_hip_trace_occluded_dev(g.device(ctx), C.c_void_p(d_rays.data_ptr()), C.c_void_p(d_ref.data_ptr()), n, 1,
+                                                    C.c_void_p(d_occ.data_ptr()), stats, C.c_void_p(st.cuda_stream)))
+        st.synchronize()
+        assert np.array_equal(d_occ.cpu().numpy(), want) and 0 < want.sum() < n
+        assert (ctx.stats()["shadow_rays"] == n) == bool(stats)

@@ -1,13 +1,21 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): kernel trace of the default bench command, then separate PMC passes (one frame in flight:
-# counters are per dispatch and must not overlap).  Output under gpurun_out/prof_*; tools/make_traffic_json.py digests it.
+# Runs on the GPU box (gpurun): rocprofv3 kernel traces and separate PMC passes of bench.py, for the default C2 line and for
+# --config C3 / C4 / C5.  One frame in flight for the counters (they are per dispatch and must not overlap).  Output under
+# gpurun_out/prof_<tag>_*; tools/make_traffic_json.py digests it into profiles/<tag>_traffic.json.
+#   tools/collect_profiles.sh r02 [C2 C3 C4 C5]
 set -e
+TAG=${1:-r02}; shift || true
+CONFIGS=${@:-C2 C3 C4 C5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="bench.py --steps 10 --warmup 2 --no-cpu-baseline"
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_kt -o kt --output-format csv -- python3 $B > gpurun_out/prof_kt.log 2>&1
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_kt1 -o kt --output-format csv -- python3 $B --streams 1 > gpurun_out/prof_kt1.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d gpurun_out/prof_pmc_a -o pmc --output-format csv -- python3 $B --streams 1 > gpurun_out/prof_pmc_a.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d gpurun_out/prof_pmc_b -o pmc --output-format csv -- python3 $B --streams 1 > gpurun_out/prof_pmc_b.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/prof_pmc_c -o pmc --output-format csv -- python3 $B --streams 1 > gpurun_out/prof_pmc_c.log 2>&1
-tail -1 gpurun_out/prof_kt.log
-ls gpurun_out/prof_kt gpurun_out/prof_pmc_a
+O=gpurun_out/prof_$TAG
+mkdir -p $O
+for C in $CONFIGS; do
+  if [ $C = C2 ]; then B="bench.py --steps 3 --warmup 1 --frames-per-step 8 --no-cpu-baseline --no-extras"; else B="bench.py --config $C --steps 1 --warmup 0 --no-cpu-baseline"; fi
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/kt_$C -o kt --output-format csv -- python3 $B > $O/kt_$C.log 2>&1
+  [ $C = C2 ] && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/kt1_$C -o kt --output-format csv -- python3 $B --streams 1 > $O/kt1_$C.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $O/pmc_a_$C -o pmc --output-format csv -- python3 $B --streams 1 > $O/pmc_a_$C.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $O/pmc_b_$C -o pmc --output-format csv -- python3 $B --streams 1 > $O/pmc_b_$C.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_c_$C -o pmc --output-format csv -- python3 $B --streams 1 > $O/pmc_c_$C.log 2>&1
+  tail -c 300 $O/kt_$C.log; echo
+done
+find $O -name "*.csv" | head -40
