@@ -23,7 +23,25 @@ def _load(name):
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
-hip = _load(os.environ.get("RT_HIP_LIB", "librt_hip.so"))     # the C ABI (include/rt_hip.h)
+class _Variant:
+    """RT_HIP_LIB=<experiment build>: entry points the experiment build lacks (tools/build_variant.sh -DRT_MINIMAL) come from the full library"""
+
+    def __init__(self, variant, full):
+        self._v, self._f = variant, full
+
+    def __getattr__(self, name):
+        try:
+            fn = getattr(self._v, name)
+        except AttributeError:
+            fn = getattr(self._f, name)
+        setattr(self, name, fn)
+        return fn
+
+
+if os.environ.get("RT_HIP_LIB"):
+    hip = _Variant(_load(os.environ["RT_HIP_LIB"]), _load("librt_hip.so"))
+else:
+    hip = _load("librt_hip.so")     # the C ABI (include/rt_hip.h)
 host = _load("librt_host.so")   # C++ host layer, flat entry points (host/rt_host_capi.cpp)
 
 d3 = C.c_double * 3

@@ -143,7 +143,7 @@ __device__ RT_OBJ_INLINE double object_hit(const DevScene &sc, int id, V3 o, V3 
   }
   if constexpr (PARAM) {
     if (type == 6) {      // RT_HIP_BEZIER
-      ParamHit h = bezier_hit(sc.beziers[k], o, d);
+      ParamHit h = bezier_solve(sc.beziers[k], sc.beziers[k].seed, o, d, false);
       u = h.u; v = h.v; return h.t;
     } else if (type == 5) { // RT_HIP_ROTATIONAL
       ParamHit h = rotational_hit(sc.rotationals[k], o, d, record);
@@ -252,6 +252,14 @@ __device__ __forceinline__ bool slab(const RayState &r, const double *bmin, cons
   return (tmin <= tmax) && (tmax > 0.0) && (tmin <= r.bound);
 }
 
+// can a Newton-solved object still matter to this ray?  Its accepted hits lie in [pmin, pmax] (rt_param.hpp: param_prune_box), in front of
+// the origin, and only those up to t_max can change the result.  Skipping the solve otherwise changes nothing but the time.
+__device__ __forceinline__ bool param_may_matter(const RayState &r, const double *pmin, const double *pmax, double t_max)
+{
+  RayState q = r; q.bound = t_max;
+  return slab(q, pmin, pmax);
+}
+
 // direct-to-LDS copy of `bytes` (rounded up to 1 KiB pieces, at most RT_CHUNK_BYTES) from a 16-byte
 // aligned global address; every lane moves 16 bytes per instruction (wave-uniform LDS base + lane*16).
 __device__ __forceinline__ void stage_chunk(const unsigned char *src, unsigned char *lds, int bytes)
@@ -302,8 +310,20 @@ struct PairQueue {
   int obj[128];                     // object id
   double t[64], u[64], v[64];       // results of the batch being folded
 };
+// one queue per wave, shared by every walk / no-tree loop of a kernel (they never run nested)
+__device__ __forceinline__ PairQueue &wave_pair_queue()
+{
+  __shared__ PairQueue s_pq[RT_WAVES_DEV];
+  return s_pq[threadIdx.x >> 6];
+}
+#ifdef RT_SOLVE_NOINLINE
+#define RT_SOLVE_INLINE __noinline__
+#else
+#define RT_SOLVE_INLINE __forceinline__
+#endif
 // solve the first min(n, 64) pairs; returns how many were solved.  All lanes call this together.
-__device__ __forceinline__ int pairs_solve(const DevScene &sc, WaveLds *lds, PairQueue &Q, int n, bool record)
+// first_only: the caller only asks WHETHER the object is hit (occlusion query without a reference point, where any hit occludes)
+__device__ RT_SOLVE_INLINE int pairs_solve(const DevScene &sc, WaveLds *lds, PairQueue &Q, int n, bool record, bool first_only = false)
 {
   const int lane = threadIdx.x & 63;
   const int nb = n < 64 ? n : 64;
@@ -313,8 +333,11 @@ __device__ __forceinline__ int pairs_solve(const DevScene &sc, WaveLds *lds, Pai
     const V3 o = mk(gr.o[0], gr.o[1], gr.o[2]), d = mk(gr.d[0], gr.d[1], gr.d[2]);
     ParamHit h;
     if (sc.obj_type[id] == 6) {
-      const DBezier B = sc.beziers[sc.obj_index[id]];                // this lane's object: a private copy in registers
-      h = bezier_hit(B, o, d);
+      const DBezier &G = sc.beziers[sc.obj_index[id]];
+      DBezierCtrl B;                                                  // this lane's control net: a private copy in registers
+      for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int a = 0; a < 3; a++) B.c[i][j][a] = G.c[i][j][a];
+      for (int a = 0; a < 3; a++) B.center[a] = G.center[a];
+      h = bezier_solve(B, G.seed, o, d, first_only);
     } else {
       const DRotational R = sc.rotationals[sc.obj_index[id]];
       h = rotational_solve(R, o, d, record);                         // the box test was the condition for queueing
@@ -382,14 +405,15 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
   ChildRef cur = sc.root;
   bool have = true;                                // `cur` holds the next node (the near child); else pop
   // Newton-solved objects met in leaves (fast walk only): queued, solved 64 pairs at a time, see PairQueue
-  __shared__ PairQueue s_pq[(PARAM && DEFER) ? RT_WAVES_DEV : 1];
-  PairQueue &PQ = s_pq[(PARAM && DEFER) ? (threadIdx.x >> 6) : 0];
+  PairQueue *pq_ptr = nullptr;
+  if constexpr (PARAM && DEFER) pq_ptr = &wave_pair_queue();
+  PairQueue &PQ = *pq_ptr;
   int nq = 0;
   auto solve_pairs = [&](int keep_below) {
     if constexpr (PARAM && DEFER) {
       const int lane = threadIdx.x & 63;
       while (nq >= keep_below && nq > 0) {
-        const int nb = pairs_solve(sc, lds, PQ, nq, record);
+        const int nb = pairs_solve(sc, lds, PQ, nq, record, ANY && __ballot(has_ref) == 0ull);
         const double bt = r.best_t;
         for (int q = 0; q < nb; q++)
           if ((int)PQ.owner[q] == lane) confirmed(PQ.t[q], PQ.obj[q], !(ANY && found), PQ.u[q], PQ.v[q]);
@@ -480,7 +504,11 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           const double gox = gr.o[0], goy = gr.o[1], goz = gr.o[2], gdx = gr.d[0], gdy = gr.d[1], gdz = gr.d[2], gbound = gr.bound;
           if (STATS && (threadIdx.x & 63) == 0) st.wave_prims += nrec;
           unsigned other = 0u;                       // records of kind 2 (spheres ...): exact test after the loop
+#ifdef RT_ABL_NOREC
+          for (int b0i = 0; b0i < 0; b0i += S) {
+#else
           for (int b0i = 0; b0i < nrec; b0i += S) {
+#endif
             if (ANY && __ballot(want && !found) == 0ull) break;      // every interested ray of the wave is occluded
             const int rec = b0i + (int)q;
             const bool valid = lane_used && rec < nrec;
@@ -508,6 +536,9 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
             while (om) { const int L = __builtin_ctzll(om); om &= om - 1ull; other |= 1u << (b0i + (int)(((unsigned)L * magic) >> 16)); }
             // ---- events back to the owners, ascending lane = ascending record per ray ----
             unsigned long long ev = __ballot(valid & (kind != 2) & (untrusted | inside));
+#ifdef RT_ABL_NOEV
+            ev = 0;
+#endif
             while (ev) {
               const int L = __builtin_ctzll(ev); ev &= ev - 1ull;
               const unsigned int owner = (unsigned int)__builtin_amdgcn_readlane((int)src, L);
@@ -550,7 +581,8 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
                 // leaf that lists it (Scene.h:352), always with the same result
                 bool push = lane_on && r.mb_id != prim;
                 if (push) r.mb_id = prim;
-                if (type == 5) { const DRotational &R = sc.rotationals[sc.obj_index[prim]]; push = push && !ref_box_miss(R.bmin, R.bmax, r.o, r.d); }
+                if (type == 5) { const DRotational &R = sc.rotationals[sc.obj_index[prim]]; push = push && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, r.bound) && rot_shells_may_matter(R, r.o, r.d, r.bound); }
+                else { const DBezier &Z = sc.beziers[sc.obj_index[prim]]; push = push && param_may_matter(r, Z.pmin, Z.pmax, r.bound); }
                 nq = pairs_push(PQ, nq, push, prim);
                 solve_pairs(64);
                 continue;
@@ -652,8 +684,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
   };
   if (!sc.has_tree) {
     if constexpr (PARAM) {
-      __shared__ PairQueue s_q[RT_WAVES_DEV];
-      PairQueue &Q = s_q[threadIdx.x >> 6];
+      PairQueue &Q = wave_pair_queue();
       const int lane = threadIdx.x & 63;
       { RayLds &me = lds->rays[lane]; me.o[0] = r.o.x; me.o[1] = r.o.y; me.o[2] = r.o.z; me.d[0] = r.d.x; me.d[1] = r.d.y; me.d[2] = r.d.z; }
       __builtin_amdgcn_wave_barrier();
@@ -671,7 +702,8 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
         const int type = uni((int)sc.obj_type[id]);
         if (type == 5) {                              // surface of revolution: box test now (Object.h:836-838), Newton later
           const DRotational &R = sc.rotationals[sc.obj_index[id]];
-          const bool want = active && !ref_box_miss(R.bmin, R.bmax, r.o, r.d);
+          // (a candidate replaces the best so far only if it is nearer by eps, Scene.h:74: hits beyond best_t cannot matter)
+          const bool want = active && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, r.best_id >= 0 ? r.best_t : kMiss) && rot_shells_may_matter(R, r.o, r.d, r.best_id >= 0 ? r.best_t : kMiss);
           if (STATS && active) st.exact_tests++;
           nq = pairs_push(Q, nq, want, id);
           drain(64);
@@ -752,8 +784,7 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
   bool found = false;
   if (!sc.has_tree) {
     if constexpr (PARAM) {
-      __shared__ PairQueue s_q[RT_WAVES_DEV];
-      PairQueue &Q = s_q[threadIdx.x >> 6];
+      PairQueue &Q = wave_pair_queue();
       const int lane = threadIdx.x & 63;
       { RayLds &me = lds->rays[lane]; me.o[0] = r.o.x; me.o[1] = r.o.y; me.o[2] = r.o.z; me.d[0] = r.d.x; me.d[1] = r.d.y; me.d[2] = r.d.z; }
       __builtin_amdgcn_wave_barrier();
@@ -772,7 +803,7 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
         const int type = uni((int)sc.obj_type[id]);
         if (type == 5) {
           const DRotational &R = sc.rotationals[sc.obj_index[id]];
-          const bool want = lane_on && !ref_box_miss(R.bmin, R.bmax, r.o, r.d);
+          const bool want = lane_on && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, t_limit) && rot_shells_may_matter(R, r.o, r.d, t_limit);
           if (STATS && lane_on) st.exact_tests++;
           nq = pairs_push(Q, nq, want, id);
           drain(64);

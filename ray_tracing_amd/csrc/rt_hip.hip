@@ -472,7 +472,7 @@ int upload(rt_hip_scene *s, const std::vector<T> &v, const T **out)
 #endif
 #define RT_WAVES (RT_BLOCK / 64)
 #ifndef RT_PARAM_MINWAVES
-#define RT_PARAM_MINWAVES 1   /* kernels with the Newton solvers compiled in: one wave per SIMD, 512 registers per lane (2 waves spill 130-380 registers) */
+#define RT_PARAM_MINWAVES 2   /* kernels with the Newton solvers compiled in: two waves per SIMD (256 registers per lane, some spills) measured faster than one (512, none) and than three */
 #endif
 
 // diagnostic only (collect_stats builds of the kernels): start/end wall-clock stamp of every wave
@@ -1262,13 +1262,14 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   for (uint32_t k = 0; k < d->n_spheres; k++) { std::memcpy(spheres[k].c, d->spheres[k].c, 24); spheres[k].r = d->spheres[k].r; }
   for (uint32_t k = 0; k < d->n_circles; k++) { std::memcpy(circles[k].p0, d->circles[k].p0, 24); std::memcpy(circles[k].n, d->circles[k].n, 24); circles[k].r = d->circles[k].r; }
   std::vector<DBezier> beziers(d->n_beziers); std::vector<DRotational> rots(d->n_rotationals);
-  for (uint32_t k = 0; k < d->n_beziers; k++) { std::memcpy(beziers[k].c, d->beziers[k].ctrl, sizeof beziers[k].c); std::memcpy(beziers[k].center, d->beziers[k].center, 24); }
+  for (uint32_t k = 0; k < d->n_beziers; k++) { std::memcpy(beziers[k].c, d->beziers[k].ctrl, sizeof beziers[k].c); std::memcpy(beziers[k].center, d->beziers[k].center, 24); param_prune_box(beziers[k]); }
   for (uint32_t k = 0; k < d->n_rotationals; k++) {
     const rt_hip_rotational &z = d->rotationals[k]; DRotational &o = rots[k];
     std::memset(&o, 0, sizeof o);
     std::memcpy(o.prof, z.profile, sizeof o.prof); std::memcpy(o.center, z.center, 24);
     o.u_range = z.u_range; o.n_prof = z.n_profile; o.u_sample_num = z.u_sample_num;
     Builder::rot_box(z, o.bmin, o.bmax);
+    param_prune_box(o); param_prune_shells(o);
   }
   std::vector<DMaterial> mats(d->n_materials);
   for (uint32_t k = 0; k < d->n_materials; k++) std::memcpy(&mats[k], &d->materials[k], sizeof(DMaterial));
@@ -1397,6 +1398,9 @@ extern "C" int rt_hip_get_profile(rt_hip_scene *s, rt_hip_profile *out, int rese
 }
 
 // launch the (STATS, PARAM) instantiation of a walk kernel
+#ifdef RT_MINIMAL   /* experiment builds (tools/build_variant.sh): only the plain instantiations, no drivers beyond rt_hip_render_whitted */
+#define RT_LAUNCH_SP(K, stats, param, grid, st, ...) hipLaunchKernelGGL((K<false, false>), grid, dim3(RT_BLOCK), 0, st, __VA_ARGS__)
+#else
 #define RT_LAUNCH_SP(K, stats, param, grid, st, ...)                                                            \
   do {                                                                                                          \
     if (param) { if (stats) hipLaunchKernelGGL((K<true, true>), grid, dim3(RT_BLOCK), 0, st, __VA_ARGS__);      \
@@ -1404,6 +1408,7 @@ extern "C" int rt_hip_get_profile(rt_hip_scene *s, rt_hip_profile *out, int rese
     else       { if (stats) hipLaunchKernelGGL((K<true, false>), grid, dim3(RT_BLOCK), 0, st, __VA_ARGS__);     \
                  else hipLaunchKernelGGL((K<false, false>), grid, dim3(RT_BLOCK), 0, st, __VA_ARGS__); }        \
   } while (0)
+#endif
 
 static inline unsigned int blocks_for(size_t n) { return (unsigned int)((n + RT_BLOCK - 1) / RT_BLOCK); }
 
@@ -1889,7 +1894,11 @@ extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *
   return RT_HIP_OK;
 }
 
+#ifndef RT_MINIMAL
 #include "rt_aa.inc"
 #include "rt_ppm.inc"
 #include "rt_godray.inc"
 #include "rt_comm.inc"
+#else
+static int godray_level(rt_hip_scene *, PathNode *, unsigned int, const unsigned int *, hipStream_t) { return RT_HIP_OK; }
+#endif
