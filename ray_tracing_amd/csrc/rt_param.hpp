@@ -211,7 +211,8 @@ RT_HD V3 rot_ds_dth(const DRotational &R, double t, double th) { P2 p = curve_pt
 RT_HD void rot_eval(const DRotational &R, double t, double th, V3 &S, V3 &dSt, V3 &dSth)
 {
   P2 p, dd; curve_eval(R, t, p, dd);
-  const double c = cos(th), s = sin(th);
+  double s, c;
+  sincos(th, &s, &c);              // one argument reduction for both (the device library's sin and cos run the same reduction and kernels)
   S = mk(p.u * c, p.u * s, p.v);
   dSt = mk(c * dd.u, s * dd.u, dd.v);
   dSth = mk(-(p.u) * s, p.u * c, 0);
