@@ -71,6 +71,24 @@ def ppm_pass_sharded(pm, pass_index, group=None, stream=None):
     pm.update(sp)
 
 
+def _render_stream(stream):
+    """the stream a render is enqueued on, ordered after what the current stream did to its buffers (allocation, zero fill)"""
+    import torch
+    cur = torch.cuda.current_stream()
+    if stream is None or stream == cur:
+        return cur
+    stream.wait_stream(cur)
+    return stream
+
+
+def _join(stream):
+    """the current stream (where the collectives below run) waits for the render on `stream`"""
+    import torch
+    cur = torch.cuda.current_stream()
+    if stream != cur:
+        cur.wait_stream(stream)
+
+
 def gather_rows(local, height, width, channels, group=None):
     """all-gather of the row blocks into the full (height*width, channels) frame on every rank"""
     import torch
@@ -103,9 +121,11 @@ def render_whitted_rows(rta, ctx, scene, camera, background=(0, 0, 0), stream=No
     local = torch.empty((count, 3), dtype=torch.float64, device="cuda")
     if count:
         p = rta.Params(background=background, pixel_first=first, pixel_count=count)
-        s = stream if stream is not None else torch.cuda.current_stream()
+        s = _render_stream(stream)
         rta.check(rta.hip.rt_hip_render_whitted_dev(scene.device(ctx), camera.raw, p, C.c_void_p(local.data_ptr()), None,
                                                     C.c_void_p(s.cuda_stream)))
+    if count:
+        _join(s)
     return gather_rows(local, camera.height, camera.width, 3, group)
 
 
@@ -119,9 +139,11 @@ def render_antialiasing_rows(rta, ctx, scene, camera, aa=None, background=(0, 0,
     local = torch.empty((count, 3), dtype=torch.float64, device="cuda")
     if count:
         p = rta.Params(background=background, seed=seed, spp=spp, lens_radius=lens_radius, pixel_first=first, pixel_count=count)
-        s = stream if stream is not None else torch.cuda.current_stream()
+        s = _render_stream(stream)
         rta.check(rta.hip.rt_hip_render_antialiasing_dev(scene.device(ctx), camera.raw, p, aa if aa is not None else rta.AaParams(),
                                                          C.c_void_p(local.data_ptr()), None, C.c_void_p(s.cuda_stream)))
+    if count:
+        _join(s)
     return gather_rows(local, camera.height, camera.width, 3, group)
 
 
@@ -134,9 +156,11 @@ def render_focusing_samples(rta, ctx, scene, camera, radius, spp, background=(0,
     acc = torch.zeros((camera.height * camera.width, 3), dtype=torch.float64, device="cuda")
     if n:
         p = rta.Params(background=background, seed=seed, spp=spp, lens_radius=radius, sample_first=s0, sample_count=n)
-        s = stream if stream is not None else torch.cuda.current_stream()
+        s = _render_stream(stream)
         rta.check(rta.hip.rt_hip_render_focusing_dev(scene.device(ctx), camera.raw, p, C.c_void_p(acc.data_ptr()),
                                                      C.c_void_p(s.cuda_stream)))
+    if n:
+        _join(s)
     return reduce_samples(acc, group)
 
 

@@ -16,8 +16,8 @@ def load(d):
         return {}
     for row in csv.DictReader(open(f[0])):
         k = row["Kernel_Name"]
-        if "<true" in k or "at::native" in k or "hipcub" in k or "rocprim" in k or "elementwise" in k:
-            continue        # statistics builds of the kernels and torch's / rocPRIM's own kernels
+        if "<true, " in k or "at::native" in k or "hipcub" in k or "rocprim" in k or "elementwise" in k:
+            continue        # statistics builds of the walk kernels (<STATS, ...>; single-parameter templates are <PARAM>) and torch's / rocPRIM's own kernels
         name = k.split("(")[0].replace("void ", "").split("<")[0]
         acc[name][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[name][row["Counter_Name"]] += 1
     return {k: dict({c: acc[k][c] / cnt[k][c] for c in acc[k]}, launches=max(cnt[k].values())) for k in acc}
