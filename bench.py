@@ -534,11 +534,12 @@ def cpu_sample(name, W, rows=2):
         _, o = scenes.build_icosahedron(material="plastic", light="area10", gpu=False)
         cam = scenes.oracle_camera(W.C3_CAMERA)
         w = 1920
+        lens = 1
         t = time.perf_counter()
-        o.render_focusing(cam, 0.1, 1, background=(200, 200, 200), seed=1, first=(540 - rows // 2) * w, count=rows * w, threads=threads)
+        o.render_focusing(cam, 0.1, lens, background=(200, 200, 200), seed=1, first=(540 - rows // 2) * w, count=rows * w, threads=threads)
         dt = time.perf_counter() - t
-        rays = rows * w * 101
-        what = "%d centre rows x 1 lens sample of the C3 frame (camera ray + 100 shadow rays each)" % rows
+        rays = rows * w * 101 * lens
+        what = "%d centre rows x %d lens sample(s) of the C3 frame (camera ray + 100 shadow rays each)" % (rows, lens)
     elif name == "C4":
         _, o = scenes.build_paper(gpu=False)
         cam = scenes.oracle_camera(W.C4_CAMERA)
@@ -553,10 +554,11 @@ def cpu_sample(name, W, rows=2):
         cam = scenes.oracle_camera(W.C5_CAMERA)
         w = 1920
         t = time.perf_counter()
-        _, _, cnt = o.render_whitted(cam, background=(10, 10, 10), first=540 * w, count=w // 4, threads=threads, counters=True)
+        npx = w // 4 if rows <= 1 else rows * w
+        _, _, cnt = o.render_whitted(cam, background=(10, 10, 10), first=540 * w, count=npx, threads=threads, counters=True)
         dt = time.perf_counter() - t
         rays = int(cnt[0])
-        what = "a quarter of the centre row of the C5 eye pass (depth 8, 25 shadow rays per hit), Whitted part only"
+        what = "%s of the C5 eye pass (depth 8, 25 shadow rays per hit), Whitted part only" % ("a quarter of the centre row" if rows <= 1 else "%d centre rows" % rows)
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": "%s: %d rays, %.2f s, oracle/rt_oracle.c with OpenMP" % (what, rays, dt)}
 
 
@@ -598,7 +600,7 @@ def main():
                                "achieved": round(res["valu_issue_frac"] * VALU_ISSUE_PEAK_G, 1) if res.get("valu_issue_frac") else None, "traffic": None,
                                "note": "from the rocprofv3 --pmc passes of this config kept in profiles/r02_traffic.json (SQ_INSTS_VALU x 4 / 1024 SIMDs / kernel cycles)"}
             if not args.no_cpu_baseline and D.world == 1:
-                out["cpu_baseline"] = cpu_sample(args.config, W, rows=540 if args.config == "C3" else 2)
+                out["cpu_baseline"] = cpu_sample(args.config, W, rows={"C3": 1080, "C4": 64, "C5": 12}[args.config])      # ~10 s of host work each
     if D.rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     D.finish()
