@@ -281,7 +281,31 @@ def bench_c2(args, D, torch, rta, W):
     if emulate:
         out["config"]["emulated"] = "rank 0's share of a %d-rank run on one GPU, no collective: value = this rank's rate x %d (a projection, not a result)" % (tw, tw)
     if world > 1 or emulate:
-        return out                          # the roofline / CPU legs belong to the one-GPU line
+        # the dominant kernel of THIS rank's share, timed live with HIP events on its stream (one launch in flight); its instruction count is
+        # the full frame's SQ_INSTS_VALU (profiles/r02_traffic.json) scaled by the rank's share of the rays.  The CPU leg belongs to N = 1.
+        if tiles_mode:
+            sptr = C.c_void_p(stream0.cuda_stream)
+            torch.cuda.synchronize()
+            rta.check(rta.hip.rt_hip_set_profiling(raw_scene, 1))
+            prof = rta.Profile()
+            rta.check(rta.hip.rt_hip_get_profile(raw_scene, C.byref(prof), 1))
+            for s_ in range(20):
+                rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cams[s_ % 32].raw, params_tile, C.c_void_p(send[0].data_ptr()), None, sptr))
+            torch.cuda.synchronize()
+            rta.check(rta.hip.rt_hip_get_profile(raw_scene, C.byref(prof), 1))
+            rta.check(rta.hip.rt_hip_set_profiling(raw_scene, 0))
+            kms = {rta.KERNEL_NAMES[i]: prof.ms[i] / prof.launches[i] for i in range(12) if prof.launches[i]}
+            dom = max(kms, key=lambda k: kms[k])
+            pmc = read_traffic(dom)
+            share = float(my_rays) / max(1.0, rays_per_frame)
+            vi = pmc.get("SQ_INSTS_VALU")
+            ach = vi * share / (kms[dom] * 1e-3) / 1e9 if vi else None
+            out["roofline"] = {"bound": "valu_issue", "kernel": dom, "achieved": round(ach, 1) if ach else None, "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instructions/s",
+                               "frac": round(ach / VALU_ISSUE_PEAK_G, 4) if ach else None, "traffic": pmc.get("hbm_bytes_per_launch") * share if pmc.get("hbm_bytes_per_launch") else None,
+                               "kernel_ms": round(kms[dom], 4), "rays_per_launch": int(my_rays), "share_of_frame": round(share, 4),
+                               "note": "rank 0's tile share of a frame, one launch in flight, HIP events on its stream; instruction and traffic counts = the one-GPU frame's "
+                                       "PMC figures x this rank's share of the rays (the counters were collected on the full frame)"}
+        return out
 
     # =========================== one GPU: roofline, secondary figures, CPU baseline ===========================
     # ---- kernel time with ONE frame in flight, HIP events on the kernel's own stream (rt_hip_set_profiling) ----
