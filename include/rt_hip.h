@@ -205,7 +205,10 @@ int rt_hip_scene_destroy(rt_hip_scene *scene);
 /* Another handle on the same scene: shares the geometry in HBM (released with the last handle), owns its
  * render workspace.  One handle serves one call at a time; two handles may render concurrently on two
  * streams.  The reference passes CScene BY VALUE into every RayTracer call (RayTracer.h:8) - a copy per ray;
- * this is the one copy per frame in flight that remains of it. */
+ * this is the one copy per frame in flight that remains of it.
+ * A handle also remembers how long every 8x8-pixel tile of its last depth-1 frame took and starts the longest tiles first when it renders
+ * the same tiling again (an animation: same size and shard, camera moved a little).  Only the order of work changes, never a result;
+ * RT_HIP_COST_ORDER=0 in the environment turns it off. */
 int rt_hip_scene_share(rt_hip_scene *scene, rt_hip_scene **out);
 
 /* ---- queries --------------------------------------------------------------------- */

@@ -112,6 +112,7 @@ struct WaveLds {
   alignas(16) unsigned char leaf[RT_CHUNK_BYTES];
   alignas(16) RayLds rays[64];
   unsigned int slot[64];                             // rank among the interested rays of a leaf -> lane
+  unsigned long long t_start;                        // k_frame_direct: the wave's start time (its cost orders the next frame's waves)
 };
 
 // uniform (scalar) copy of a value that is known to be the same in all lanes

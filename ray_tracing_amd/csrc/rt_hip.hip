@@ -95,6 +95,8 @@ struct rt_hip_scene {
   DevBuf levels[kMaxLevels];
   DevBuf order;                   // heavy-first wave order lists + flags
   DevBuf lum;                     // per node, per light luminosity (shadow pass -> shade pass)
+  DevBuf wave_cost;               // k_frame_direct: run time of every wave of the last depth-1 frame (k_cost_order)
+  uint64_t cost_sig[6] = {0, 0, 0, 0, 0, 0};   // the tiling those costs belong to (0: none)
   DevBuf counter;                 // queue counter + per-render ray counters
   DevBuf staging;                 // host-pointer entry points
   uint64_t last_rays = 0, last_shadow = 0;
@@ -597,6 +599,7 @@ struct RenderArgs {
   uint32_t tile_offset, tile_stride, n_st;
   uint32_t out_bgr8;                  // the frame goes out as the reference's Vec3b picture (Camera.h:69) instead of f64 R,G,B
   uint64_t n_out, n_primary;          // entries of the output arrays; camera rays of this call
+  unsigned int *wave_cost;            // k_frame_direct: where a wave leaves its run time in cycles (NULL: nowhere), see k_cost_order
 };
 
 // ---- heavy-first work order --------------------------------------------------------------------
@@ -775,6 +778,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   const unsigned int slot = xcd_remap(blockIdx.x, gridDim.x) * RT_WAVES + (threadIdx.x >> 6);
   const unsigned int wave = order ? (unsigned int)uni((int)order[slot]) : slot;
   const unsigned int lane = threadIdx.x & 63;
+  if (A.wave_cost && lane == 0) stack->t_start = __builtin_readcyclecounter();     // kept in LDS: no register lives across the walks for it
   unsigned int s_local, tx, ty; tile_of_wave(A, wave, s_local, tx, ty);
   const unsigned int h = tx * 8 + (lane & 7);
   const unsigned int v = A.v_lo + ty * 8 + (lane >> 3);
@@ -833,6 +837,10 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   const unsigned long long my_shadow = per_hit * (unsigned long long)__popcll(__ballot(hit));
   if (lane == 0 && my_shadow) atomicAdd(&cnt->shadow_rays, my_shadow);
   if (STATS) stats_flush(gstats, st);
+  if (A.wave_cost && lane == 0) {
+    const unsigned long long dt = __builtin_readcyclecounter() - stack->t_start;
+    A.wave_cost[wave] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned int)dt;
+  }
 }
 
 // index of the level-0 node of raster pixel p (inverse of k_primary's tile numbering)
@@ -1144,7 +1152,7 @@ extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
   for (auto &e : s->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &b : s->levels) b.release();
   for (auto &b : s->uv) b.release();
-  s->counter.release(); s->staging.release(); s->lum.release(); s->order.release(); s->aa_maps.release(); s->aa_edges.release(); s->aa_mask.release();
+  s->counter.release(); s->staging.release(); s->lum.release(); s->wave_cost.release(); s->order.release(); s->aa_maps.release(); s->aa_edges.release(); s->aa_mask.release();
   ctx_release(s->ctx);
   delete s;
   return RT_HIP_OK;
@@ -1619,7 +1627,7 @@ static int level_counts(rt_hip_scene *s)
 
 
 // bytes of the heavy-first order workspace for n_waves level-0 waves: two order lists, the per-block counts, two flag arrays
-static inline size_t order_bytes(uint64_t n_waves) { return (size_t)n_waves * 10 + (size_t)((n_waves + 1023) / 1024) * 4 + 64; }
+static inline size_t order_bytes(uint64_t n_waves) { return (size_t)n_waves * 10 + (size_t)((n_waves + 1023) / 1024) * 128 + 64; }      // (x 128: k_cost_count's 32 classes per block)
 struct OrderBufs { unsigned int *order0 = nullptr, *order1 = nullptr, *ocounts = nullptr; unsigned char *flags0 = nullptr, *flags1 = nullptr; unsigned int oblocks = 0; };
 // classification of the level-0 waves + their heavy-first order (k_classify, k_order_count, k_order) in `mem` (order_bytes(n_waves))
 static int order_waves(rt_hip_scene *s, const RenderArgs &A, uint64_t n_waves, void *mem, hipStream_t st, OrderBufs &O, bool prof)
@@ -1635,6 +1643,62 @@ static int order_waves(rt_hip_scene *s, const RenderArgs &A, uint64_t n_waves, v
   HIP_TRY(hipGetLastError());
   return RT_HIP_OK;
 }
+// ---- longest-first order from the previous frame's wave costs --------------------------------------------------------------
+// Heavy-first knows two classes.  Within the heavy class wave costs still differ 20x (a tile at the horizon walks ten times the leaves of a
+// tile at the viewer's feet), and the last long waves of a launch run on an almost empty GPU.  A renderer's frames come in sequences: the
+// same handle renders the same tiling again with a camera that has moved a little, so the time each wave took LAST time (k_frame_direct
+// leaves it in wave_cost) is a good estimate of what it will take now.  k_cost_count / k_cost_order list the waves by cost class, longest first,
+// 32 classes half an octave apart, stably (neighbouring tiles stay neighbours inside a class: they share leaves in L2).  Results do not depend
+// on the order; a stale or missing cost array only costs time.
+// cost class: 0 = the longest; half an octave per class over 2^24 .. 2^8 cycles (absolute, so that blocks need not agree on a maximum first)
+__device__ __forceinline__ unsigned int cost_class(unsigned int c)
+{
+  if (c == 0) return 31u;
+  const int k = 48 - (int)(2.0f * __log2f((float)c));
+  return (unsigned int)(k < 0 ? 0 : (k > 31 ? 31 : k));
+}
+// two small launches, 1024 waves per block, like k_order_count / k_order:
+//   k_cost_count : entries per class and block
+//   k_cost_order : every block sums what lies before its entries of each class (all blocks' lower classes + earlier blocks' same class) and places them
+__global__ void __launch_bounds__(1024) k_cost_count(const unsigned int *cost, unsigned int n, unsigned int *counts)
+{
+  __shared__ unsigned int s_h[32];
+  const unsigned int t = threadIdx.x, i = blockIdx.x * 1024 + t;
+  if (t < 32) s_h[t] = 0;
+  __syncthreads();
+  if (i < n) atomicAdd(&s_h[cost_class(cost[i])], 1u);
+  __syncthreads();
+  if (t < 32) counts[blockIdx.x * 32 + t] = s_h[t];
+}
+__global__ void __launch_bounds__(1024) k_cost_order(const unsigned int *cost, unsigned int n, const unsigned int *counts, unsigned int *order)
+{
+  __shared__ unsigned int s_tot[32], s_before[32], s_base[32], s_wc[16][32];
+  const unsigned int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < 32) {                                   // class t: entries in all blocks, and in the blocks before this one
+    unsigned int tot = 0, bef = 0;
+    for (unsigned int b = 0; b < gridDim.x; b++) { const unsigned int c = counts[b * 32 + t]; tot += c; if (b < blockIdx.x) bef += c; }
+    s_tot[t] = tot; s_before[t] = bef;
+  }
+  __syncthreads();
+  if (t == 0) { unsigned int a = 0; for (int k = 0; k < 32; k++) { s_base[k] = a + s_before[k]; a += s_tot[k]; } }
+  const unsigned int i = blockIdx.x * 1024 + t;
+  const bool valid = i < n;
+  const unsigned int c = valid ? cost_class(cost[i]) : 32u;
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  unsigned int my_rank = 0;
+  for (unsigned int b = 0; b < 32; b++) {
+    const unsigned long long m = __ballot(c == b);
+    if (lane == 0) s_wc[w][b] = (unsigned int)__popcll(m);
+    if (c == b) my_rank = (unsigned int)__popcll(m & below);
+  }
+  __syncthreads();
+  if (valid) {
+    unsigned int before = 0;
+    for (unsigned int k = 0; k < w; k++) before += s_wc[k][c];
+    order[s_base[c] + before + my_rank] = i;
+  }
+}
+
 // does the depth-1 frame take the loop-free kernel (one light of one sample: the luminosity stays in a register, no lum array)?
 static inline bool frame_direct_one(const rt_hip_scene *s, bool stats) { return !stats && !s->dev.has_param && s->one_sample; }
 // a depth-1 frame in one launch (k_frame_direct); lum: n0 * n_lights doubles, needed unless frame_direct_one()
@@ -1658,6 +1722,8 @@ static int launch_frame_direct(rt_hip_scene *s, const RenderArgs &A, bool stats,
   s->last_rays += A.n_primary;
   return RT_HIP_OK;
 }
+// RT_HIP_COST_ORDER=0 in the environment keeps the two-class heavy-first order for every frame (A/B runs)
+static const bool g_cost_order = []{ const char *e = std::getenv("RT_HIP_COST_ORDER"); return !(e && e[0] == '0'); }();
 static inline uint64_t level0_waves(const RenderArgs &A) { return (uint64_t)A.n_st * 128 * A.n_samples; }
 
 // the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
@@ -1672,14 +1738,32 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
   // heavy-first order of the level-0 waves (only worth it with a tree)
   OrderBufs O;
+  const int cam_depth = A.cam.depth < 1 ? 1 : A.cam.depth;
+  const bool direct = direct_rgb && cam_depth == 1 && s->dev.n_lights > 0 && !s->god && !s->keep_uv && !A.focusing && A.n_samples == 1;
+  // a depth-1 frame of a tiling this handle has rendered before: longest-first by the waves' last run times (k_cost_order)
+  const uint64_t sig[6] = {n_waves, ((uint64_t)A.cam.W << 32) | (uint64_t)A.cam.H, ((uint64_t)A.tile_offset << 32) | A.tile_stride, A.pixel_first, A.pixel_count, (uint64_t)A.v_lo + 1};
+  const bool by_cost = direct && s->dev.has_tree && !stats && g_cost_order && n_waves <= (1u << 18) && std::memcmp(sig, s->cost_sig, sizeof sig) == 0;
   if (s->dev.has_tree) {
     rc = s->order.ensure(order_bytes(n_waves)); if (rc) return rc;
-    rc = order_waves(s, A, n_waves, s->order.p, st, O, true); if (rc) return rc;
+    if (by_cost) {
+      O.order0 = (unsigned int *)s->order.p;
+      ProfScope scope(s, RT_HIP_K_ORDER, st);
+      const unsigned int cb = (unsigned int)((n_waves + 1023) / 1024);
+      unsigned int *ccounts = O.order0 + 2 * n_waves;               // (the place of the heavy-first lists' counts and flags: n_waves * 2 bytes + ...)
+      hipLaunchKernelGGL(k_cost_count, dim3(cb), dim3(1024), 0, st, (const unsigned int *)s->wave_cost.p, (unsigned int)n_waves, ccounts);
+      hipLaunchKernelGGL(k_cost_order, dim3(cb), dim3(1024), 0, st, (const unsigned int *)s->wave_cost.p, (unsigned int)n_waves, (const unsigned int *)ccounts, O.order0);
+      HIP_TRY(hipGetLastError());
+    } else { rc = order_waves(s, A, n_waves, s->order.p, st, O, true); if (rc) return rc; }
   }
-  const int cam_depth = A.cam.depth < 1 ? 1 : A.cam.depth;
-  if (direct_rgb && cam_depth == 1 && s->dev.n_lights > 0 && !s->god && !s->keep_uv && !A.focusing && A.n_samples == 1) {
+  if (direct) {
     if (!frame_direct_one(s, stats)) { rc = s->lum.ensure((size_t)n0 * s->dev.n_lights * sizeof(double)); if (rc) return rc; }
-    return launch_frame_direct(s, A, stats, st, n_waves, O.order0, (double *)s->lum.p, (RenderCounters *)s->counter.p, direct_rgb, direct_id, true);
+    RenderArgs B = A;
+    if (s->dev.has_tree && !stats && g_cost_order && n_waves <= (1u << 18)) {
+      rc = s->wave_cost.ensure((size_t)n_waves * sizeof(unsigned int)); if (rc) return rc;
+      B.wave_cost = (unsigned int *)s->wave_cost.p;
+      std::memcpy(s->cost_sig, sig, sizeof sig);
+    }
+    return launch_frame_direct(s, B, stats, st, n_waves, O.order0, (double *)s->lum.p, (RenderCounters *)s->counter.p, direct_rgb, direct_id, true);
   }
   rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
   PathNode *L0 = (PathNode *)s->levels[0].p;
@@ -1702,6 +1786,7 @@ static int fill_args(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_par
 {
   if (!s || !P) return fail(RT_HIP_EINVAL, "NULL argument");
   if (P->struct_size != sizeof(rt_hip_params)) return fail(RT_HIP_EINVAL, "rt_hip_params.struct_size mismatch");
+  A->wave_cost = nullptr;
   int rc = camera_setup(cam, &A->cam); if (rc) return rc;
   const uint64_t total = (uint64_t)A->cam.W * A->cam.H;
   A->pixel_first = P->pixel_count ? P->pixel_first : 0;

@@ -188,3 +188,23 @@ def test_trace_occluded_dev_matches_host_entry(ctx):
         st.synchronize()
         assert np.array_equal(d_occ.cpu().numpy(), want) and 0 < want.sum() < n
         assert (ctx.stats()["shadow_rays"] == n) == bool(stats)
+
+
+def test_repeated_frames_on_one_handle_are_identical(ctx):
+    """from its second depth-1 frame on a handle orders the waves by the run times they left last time (k_cost_order): only the
+    schedule changes, the frames stay bit-identical, also when the camera moves in between and when the tiling changes"""
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(material="plastic", light="point_area", oracle=False)
+    cams = [rta.Camera(**dict(scenes.C1_CAMERA, depth=1)), rta.Camera(**dict(scenes.C1_CAMERA, depth=1, view=(-10.2, 0.3, 1.4))),
+            rta.Camera(**dict(scenes.C1_CAMERA, depth=1, res=60))]
+    first = []
+    for cam in cams:
+        cam.render_raytracer(ctx, g, background=(200, 200, 200))
+        first.append((cam.rgb().copy(), cam.prim_id().copy()))
+    for rep in range(3):
+        for cam, (rgb, ids) in zip(cams, first):
+            cam.render_raytracer(ctx, g, background=(200, 200, 200))
+            assert np.array_equal(cam.rgb(), rgb) and np.array_equal(cam.prim_id(), ids)
+        # the same camera twice in a row: the second frame runs on the first one's costs
+        cams[0].render_raytracer(ctx, g, background=(200, 200, 200))
+        assert np.array_equal(cams[0].rgb(), first[0][0])
