@@ -401,6 +401,10 @@ int rt_hip_get_profile(rt_hip_scene *scene, rt_hip_profile *out, int reset);
 
 /* number of rays (closest-hit + occlusion queries) issued by the last render call on this scene */
 int rt_hip_last_ray_count(rt_hip_scene *scene, uint64_t *rays, uint64_t *shadow_rays);
+/* Diagnostic, no counterpart in the reference: shader-clock cycles every wave (8x8-pixel tile, in the library's tile order: 128x64-pixel
+ * super-tiles row by row, 16x8 tiles inside each) of this handle's last depth-1 frame was resident - the figures that order the next frame's
+ * work (rt_hip_scene_share).  *n_waves = number of entries (0: no such frame yet); out may be NULL to ask for the size.  Synchronises the device. */
+int rt_hip_last_wave_costs(rt_hip_scene *scene, uint32_t *out, uint64_t cap, uint64_t *n_waves);
 
 #ifdef __cplusplus
 }

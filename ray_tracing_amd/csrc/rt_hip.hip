@@ -1979,6 +1979,18 @@ extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *
   return RT_HIP_OK;
 }
 
+extern "C" int rt_hip_last_wave_costs(rt_hip_scene *s, uint32_t *out, uint64_t cap, uint64_t *n_waves)
+{
+  if (!s || !n_waves) return fail(RT_HIP_EINVAL, "NULL argument");
+  *n_waves = s->cost_sig[0];
+  if (!out || s->cost_sig[0] == 0) return RT_HIP_OK;
+  if (cap < s->cost_sig[0]) return fail(RT_HIP_EINVAL, "rt_hip_last_wave_costs: room for " + std::to_string(cap) + " entries, the frame had " + std::to_string(s->cost_sig[0]) + " waves");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, s->wave_cost.p, (size_t)s->cost_sig[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return RT_HIP_OK;
+}
+
 #ifndef RT_MINIMAL
 #include "rt_aa.inc"
 #include "rt_ppm.inc"

@@ -194,6 +194,7 @@ def test_repeated_frames_on_one_handle_are_identical(ctx):
     """from its second depth-1 frame on a handle orders the waves by the run times they left last time (k_cost_order): only the
     schedule changes, the frames stay bit-identical, also when the camera moves in between and when the tiling changes"""
     import ray_tracing_amd as rta
+    from ray_tracing_amd import parallel
     g, _ = scenes.build_icosahedron(material="plastic", light="point_area", oracle=False)
     cams = [rta.Camera(**dict(scenes.C1_CAMERA, depth=1)), rta.Camera(**dict(scenes.C1_CAMERA, depth=1, view=(-10.2, 0.3, 1.4))),
             rta.Camera(**dict(scenes.C1_CAMERA, depth=1, res=60))]
@@ -208,3 +209,11 @@ def test_repeated_frames_on_one_handle_are_identical(ctx):
         # the same camera twice in a row: the second frame runs on the first one's costs
         cams[0].render_raytracer(ctx, g, background=(200, 200, 200))
         assert np.array_equal(cams[0].rgb(), first[0][0])
+    # rt_hip_last_wave_costs: one entry per 8x8 tile of the padded super-tile grid, every wave has been resident for some cycles
+    nw = C.c_uint64()
+    rta.check(rta.hip.rt_hip_last_wave_costs(g.device(ctx), None, 0, C.byref(nw)))
+    assert nw.value == parallel.tile_shard_counts(cams[0].width, cams[0].height, 1)[0] * 128
+    cost = np.zeros(nw.value, dtype=np.uint32)
+    rta.check(rta.hip.rt_hip_last_wave_costs(g.device(ctx), C.c_void_p(cost.ctypes.data), nw.value, C.byref(nw)))
+    assert (cost > 0).all() and cost.max() > 4 * np.median(cost)        # the tiles on the mesh take several times the background tiles' time
+    assert rta.hip.rt_hip_last_wave_costs(g.device(ctx), C.c_void_p(cost.ctypes.data), 5, C.byref(nw)) == -1
