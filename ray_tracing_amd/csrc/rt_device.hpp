@@ -507,6 +507,10 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           const unsigned int q = (lane * magic) >> 16, j = lane - q * (unsigned)n;
           const int S = (int)((64u * magic) >> 16);          // records in flight per step = 64 / n
           const bool lane_used = (int)q < S;
+          // bits 0, n, 2n, ... (S of them): the lanes that hold the records of the ray of rank 0; shifted by k for the ray of rank k
+          unsigned long long stride_mask = 1ull;
+          for (int span = n; span < S * n; span <<= 1) stride_mask |= stride_mask << span;
+          if (S * n < 64) stride_mask &= (1ull << (S * n)) - 1ull;
           const unsigned int src = lds->slot[j];
           const RayLds &gr = lds->rays[src];
           const double gox = gr.o[0], goy = gr.o[1], goz = gr.o[2], gdx = gr.d[0], gdy = gr.d[1], gdz = gr.d[2], gbound = gr.bound;
@@ -539,16 +543,25 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
             unsigned long long om = __ballot(valid & (kind == 2) & (j == 0u));
             while (om) { const int L = __builtin_ctzll(om); om &= om - 1ull; other |= 1u << (b0i + (int)(((unsigned)L * magic) >> 16)); }
             // ---- events back to the owners, ascending lane = ascending record per ray ----
-            unsigned long long ev = __ballot(valid & (kind != 2) & (untrusted | inside));
-            while (ev) {
-              const int L = __builtin_ctzll(ev); ev &= ev - 1ull;
-              const unsigned int owner = (unsigned int)__builtin_amdgcn_readlane((int)src, L);
-              const int eprim = __builtin_amdgcn_readlane(prim, L);
-              const int eun = __builtin_amdgcn_readlane(untrusted ? 1 : 0, L);
-              const unsigned long long tbits = __double_as_longlong(tc);
-              const double etc = __longlong_as_double(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(tbits >> 32), L) << 32) |
-                                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)tbits, L));
-              if (lane == owner && !(ANY && found)) {
+            const unsigned long long ev = __ballot(valid & (kind != 2) & (untrusted | inside));
+            // Every owner takes ITS events together with the other owners: the events of the ray of rank k sit in lanes k, k + n, k + 2n, ...
+            // (ascending lane = ascending record), so an owner masks ev with that stride pattern and pulls the (t', prim, untrusted) of its
+            // lowest event from the lane that holds it with ds_bpermute; one round per event of the busiest ray of the step (mostly one),
+            // where the former loop took one round per event of the step (~5).
+            unsigned long long mine = want ? (ev & (stride_mask << rank)) : 0ull;
+            const unsigned long long tbits = __double_as_longlong(tc);
+            const int pack = prim | (untrusted ? (int)0x80000000 : 0);
+            while (__ballot(mine != 0ull) != 0ull) {
+              const bool has = mine != 0ull;
+              const int L = has ? (int)__builtin_ctzll(mine) : 0;
+              mine &= mine - 1ull;
+              const int epack = __builtin_amdgcn_ds_bpermute(L << 2, pack);
+              const unsigned int ehi = (unsigned int)__builtin_amdgcn_ds_bpermute(L << 2, (int)(tbits >> 32));
+              const unsigned int elo = (unsigned int)__builtin_amdgcn_ds_bpermute(L << 2, (int)(unsigned)tbits);
+              const double etc = __longlong_as_double(((unsigned long long)ehi << 32) | (unsigned long long)elo);
+              const int eprim = epack & 0x7FFFFFFF;
+              const bool eun = epack < 0;
+              if (has && !(ANY && found)) {
                 if (eun) D.redo = true;
                 else if (etc < r.bound + r.tmargin) {          // the owner's current bound (the gathered one may be older)
                   if (ANY) {
