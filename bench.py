@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--leaf-refine", type=int, default=None, help="rt_hip_scene_create leaf_refine (include/rt_hip.h; default: the library's own hierarchy)")
     ap.add_argument("--mode", choices=["tiles", "replicas"], default="tiles")
     ap.add_argument("--comm", choices=["abi", "torch"], default="abi", help="data-path collective: rt_hip_comm_* (RCCL behind the C ABI) or torch.distributed")
-    ap.add_argument("--streams", type=int, default=0, help="frames in flight per GPU (0 = 4, one per hardware queue)")
+    ap.add_argument("--streams", type=int, default=0, help="frames in flight per GPU (0 = 4, or 8 from 8 ranks on: one per hardware queue)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU: collectives then run on HOST tensors)")
     ap.add_argument("--emulate-world", type=int, default=0, help="one GPU renders rank 0's share of an N-rank run, no collective (tuning aid; not a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,7 +168,7 @@ def bench_c2(args, D, torch, rta, W):
     emulate = args.emulate_world if world == 1 else 0
     tw = emulate or world                                   # ranks the frame is split over
     tiles_mode = args.mode == "tiles" and tw > 1
-    S = args.streams or 4        # frames in flight: one per hardware queue (GPU_MAX_HW_QUEUES = 4); measured 2: 5.63, 3: 5.87, 4: 6.11, 6: 5.81, 8: 6.00 Grays/s
+    S = args.streams or (8 if tw >= 8 else 4)   # frames in flight: one per hardware queue (main()); N = 1 measured 2: 5.63, 3: 5.87, 4: 6.11, 6: 5.81, 8: 6.00 Grays/s
     F = max(1, args.frames_per_step)
     G = max(S, min(args.sub_batch, F))
     while F % G:
@@ -591,6 +591,11 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
 
+    # an eighth of a frame fills the GPU's wave slots once and lasts as long as its slowest tile: from 8 ranks on, 8 frames in flight
+    # on 8 hardware queues (HIP's default is 4) instead of 4 on 4; measured with --emulate-world 8: 39.4 -> 44.8 Grays/s projected
+    if max(int(os.environ.get("WORLD_SIZE", "1")), args.emulate_world) >= 8:
+        if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
     import torch
     import ray_tracing_amd as rta
     from ray_tracing_amd import workloads as W

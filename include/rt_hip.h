@@ -208,7 +208,7 @@ int rt_hip_scene_destroy(rt_hip_scene *scene);
  * this is the one copy per frame in flight that remains of it.
  * A handle also remembers how long every 8x8-pixel tile of its last depth-1 frame took and starts the longest tiles first when it renders
  * the same tiling again (an animation: same size and shard, camera moved a little).  Only the order of work changes, never a result;
- * RT_HIP_COST_ORDER=0 in the environment turns it off. */
+ * RT_HIP_COST_ORDER=0 in the environment turns it off (it is used from about 25,000 tiles per launch on: smaller launches have no tail worth filling). */
 int rt_hip_scene_share(rt_hip_scene *scene, rt_hip_scene **out);
 
 /* ---- queries --------------------------------------------------------------------- */

@@ -1722,8 +1722,9 @@ static int launch_frame_direct(rt_hip_scene *s, const RenderArgs &A, bool stats,
   s->last_rays += A.n_primary;
   return RT_HIP_OK;
 }
-// RT_HIP_COST_ORDER=0 in the environment keeps the two-class heavy-first order for every frame (A/B runs)
-static const bool g_cost_order = []{ const char *e = std::getenv("RT_HIP_COST_ORDER"); return !(e && e[0] == '0'); }();
+// RT_HIP_COST_ORDER in the environment (read per call): 0 keeps the two-class heavy-first order for every frame (A/B runs), 2 uses the
+// last frame's costs whatever the size of the launch (tests on small frames); otherwise the size rule below decides
+static inline int cost_order_mode() { const char *e = std::getenv("RT_HIP_COST_ORDER"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }
 static inline uint64_t level0_waves(const RenderArgs &A) { return (uint64_t)A.n_st * 128 * A.n_samples; }
 
 // the wavefront Whitted integrator for one batch of (pixels x samples); leaves final colours in level 0
@@ -1742,8 +1743,14 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   const bool direct = direct_rgb && cam_depth == 1 && s->dev.n_lights > 0 && !s->god && !s->keep_uv && !A.focusing && A.n_samples == 1;
   // a depth-1 frame of a tiling this handle has rendered before: longest-first by the waves' last run times (k_cost_order)
   const uint64_t sig[6] = {n_waves, ((uint64_t)A.cam.W << 32) | (uint64_t)A.cam.H, ((uint64_t)A.tile_offset << 32) | A.tile_stride, A.pixel_first, A.pixel_count, (uint64_t)A.v_lo + 1};
-  const bool by_cost = direct && s->dev.has_tree && !stats && g_cost_order && n_waves <= (1u << 18) && std::memcmp(sig, s->cost_sig, sizeof sig) == 0;
-  if (s->dev.has_tree) {
+  // (worth it from about six rounds of the GPU's 4,096 wave slots on: measured on C2, the full frame's 32,640 waves gain 3 %, a half frame's
+  // 16,320 lose 4 % -- fewer rounds leave less of a tail to fill, and the cost order runs fewer neighbouring tiles together)
+  const int cost_mode = cost_order_mode();
+  const bool cost_sized = cost_mode != 0 && (cost_mode == 2 || n_waves >= 6u * 4096u) && n_waves <= (1u << 18);
+  const bool by_cost = direct && s->dev.has_tree && !stats && cost_sized && std::memcmp(sig, s->cost_sig, sizeof sig) == 0;
+  // a launch that fits the wave slots twice over starts (nearly) all its waves at once: no order to compute
+  const bool ordered = s->dev.has_tree && (by_cost || !(direct && n_waves <= 2u * 4096u));
+  if (ordered) {
     rc = s->order.ensure(order_bytes(n_waves)); if (rc) return rc;
     if (by_cost) {
       O.order0 = (unsigned int *)s->order.p;
@@ -1758,7 +1765,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   if (direct) {
     if (!frame_direct_one(s, stats)) { rc = s->lum.ensure((size_t)n0 * s->dev.n_lights * sizeof(double)); if (rc) return rc; }
     RenderArgs B = A;
-    if (s->dev.has_tree && !stats && g_cost_order && n_waves <= (1u << 18)) {
+    if (s->dev.has_tree && !stats && cost_sized) {
       rc = s->wave_cost.ensure((size_t)n_waves * sizeof(unsigned int)); if (rc) return rc;
       B.wave_cost = (unsigned int *)s->wave_cost.p;
       std::memcpy(s->cost_sig, sig, sizeof sig);

@@ -190,11 +190,12 @@ def test_trace_occluded_dev_matches_host_entry(ctx):
         assert (ctx.stats()["shadow_rays"] == n) == bool(stats)
 
 
-def test_repeated_frames_on_one_handle_are_identical(ctx):
+def test_repeated_frames_on_one_handle_are_identical(ctx, monkeypatch):
     """from its second depth-1 frame on a handle orders the waves by the run times they left last time (k_cost_order): only the
     schedule changes, the frames stay bit-identical, also when the camera moves in between and when the tiling changes"""
     import ray_tracing_amd as rta
     from ray_tracing_amd import parallel
+    monkeypatch.setenv("RT_HIP_COST_ORDER", "2")          # these frames are smaller than the size from which the library does it by itself
     g, _ = scenes.build_icosahedron(material="plastic", light="point_area", oracle=False)
     cams = [rta.Camera(**dict(scenes.C1_CAMERA, depth=1)), rta.Camera(**dict(scenes.C1_CAMERA, depth=1, view=(-10.2, 0.3, 1.4))),
             rta.Camera(**dict(scenes.C1_CAMERA, depth=1, res=60))]
