@@ -216,9 +216,9 @@ def bench_c2(args, D, torch, rta, W):
                 recv[set_i].copy_(h_recv)
             else:
                 D.dist.all_gather_into_tensor(recv[set_i], send[set_i])
-            for g in range(G):
-                rta.check(rta.hip.rt_hip_tiles_to_frame_dev(cam0.raw, tw, C.c_void_p(recv[set_i].data_ptr() + g * blk), G * blk, 3,
-                                                            C.c_void_p(frames[set_i][g].data_ptr()), C.c_void_p(comm_stream.cuda_stream)))
+            # the G frames of the sub-batch into raster order, one launch
+            rta.check(rta.hip.rt_hip_tiles_to_frames_dev(cam0.raw, tw, C.c_void_p(recv[set_i].data_ptr()), G * blk, 3, G, blk,
+                                                         C.c_void_p(frames[set_i].data_ptr()), npix * 3, C.c_void_p(comm_stream.cuda_stream)))
             gather_done[set_i].record(comm_stream)
 
     def one_step(step):

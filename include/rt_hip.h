@@ -265,6 +265,10 @@ int rt_hip_tile_shard_info(const rt_hip_camera *cam, uint32_t tile_stride, uint3
  * This is the store picture.at<Vec3b>(v,h) of Camera.h:69 for tiles rendered elsewhere. */
 int rt_hip_tiles_to_frame_dev(const rt_hip_camera *cam, uint32_t tile_stride, const void *d_tiles, uint64_t rank_pitch_bytes,
                               uint32_t elem_bytes, void *d_frame, void *stream);
+/* The same for n_frames frames in one launch, when every rank contributed several frames to one all-gather: frame g of rank r starts at
+ * d_tiles + r * rank_pitch_bytes + g * tiles_frame_pitch_bytes and goes to d_frames + g * frame_pitch_bytes (pitches 0 = tightly packed). */
+int rt_hip_tiles_to_frames_dev(const rt_hip_camera *cam, uint32_t tile_stride, const void *d_tiles, uint64_t rank_pitch_bytes, uint32_t elem_bytes,
+                               uint32_t n_frames, uint64_t tiles_frame_pitch_bytes, void *d_frames, uint64_t frame_pitch_bytes, void *stream);
 
 /* CCamera::Render_Focusing (Camera.h:171-199): spp lens samples per pixel.  The output is the SUM over
  * the sample shard of sample_colour/spp WITHOUT the running clamp, so that shards add up

@@ -174,6 +174,7 @@ hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTE
 hip.rt_hip_render_whitted_noalloc.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_tile_shard_info.argtypes = [C.POINTER(CameraStruct), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
 hip.rt_hip_tiles_to_frame_dev.argtypes = [C.POINTER(CameraStruct), C.c_uint32, _vp, C.c_uint64, C.c_uint32, _vp, _vp]
+hip.rt_hip_tiles_to_frames_dev.argtypes = [C.POINTER(CameraStruct), C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _vp, C.c_uint64, _vp]
 hip.rt_hip_comm_unique_id.argtypes = [_vp]
 hip.rt_hip_comm_create.argtypes = [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]
 hip.rt_hip_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -1053,10 +1053,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_resolve(const PathNode *nodes, Ren
 // rt_hip_tiles_to_frame_dev: the all-gathered tile shards (rank-major: tile_stride blocks of per_rank super-tiles of
 // 128 x 64 entries) back into the raster frame
 __global__ void __launch_bounds__(256) k_tiles_to_frame(const unsigned char *tiles, unsigned int W, unsigned int H, unsigned int stride, uint64_t rank_pitch,
-                                                        unsigned int elem, unsigned char *frame)
+                                                        unsigned int elem, unsigned char *frame, uint64_t tiles_frame_pitch, uint64_t frame_pitch)
 {
   const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= (uint64_t)W * H) return;
+  tiles += (uint64_t)blockIdx.y * tiles_frame_pitch; frame += (uint64_t)blockIdx.y * frame_pitch;       // blockIdx.y: frame of a batch
   const unsigned int h = (unsigned int)(p % W), v = (unsigned int)(p / W);
   const unsigned int sx = ((W + 7) / 8 + 15) / 16;
   const unsigned int st_i = (v / 64) * sx + h / 128;
@@ -1896,21 +1897,36 @@ extern "C" int rt_hip_tile_shard_info(const rt_hip_camera *cam, uint32_t tile_st
   if (per_rank) *per_rank = (sx * sy + tile_stride - 1) / tile_stride;
   return RT_HIP_OK;
 }
-extern "C" int rt_hip_tiles_to_frame_dev(const rt_hip_camera *cam, uint32_t tile_stride, const void *d_tiles, uint64_t rank_pitch_bytes, uint32_t elem_bytes,
-                                         void *d_frame, void *stream)
+extern "C" int rt_hip_tiles_to_frames_dev(const rt_hip_camera *cam, uint32_t tile_stride, const void *d_tiles, uint64_t rank_pitch_bytes, uint32_t elem_bytes,
+                                          uint32_t n_frames, uint64_t tiles_frame_pitch_bytes, void *d_frames, uint64_t frame_pitch_bytes, void *stream)
 {
   DevCamera k; int rc = camera_setup(cam, &k); if (rc) return rc;
-  if (!d_tiles || !d_frame || elem_bytes == 0 || elem_bytes > 256) return fail(RT_HIP_EINVAL, "rt_hip_tiles_to_frame_dev: bad argument");
+  if (!d_tiles || !d_frames || elem_bytes == 0 || elem_bytes > 256 || n_frames == 0 || n_frames > 65535) return fail(RT_HIP_EINVAL, "rt_hip_tiles_to_frames_dev: bad argument");
   if (tile_stride == 0) tile_stride = 1;
   uint32_t total = 0, per_rank = 0;
   rc = rt_hip_tile_shard_info(cam, tile_stride, &total, &per_rank); if (rc) return rc;
   const uint64_t npix = (uint64_t)k.W * k.H, shard = (uint64_t)per_rank * 8192 * elem_bytes;
-  if (rank_pitch_bytes == 0) rank_pitch_bytes = shard;
-  if (rank_pitch_bytes < shard || (elem_bytes % 4 == 0 && rank_pitch_bytes % 8)) return fail(RT_HIP_EINVAL, "rt_hip_tiles_to_frame_dev: rank_pitch_bytes too small or misaligned");
-  hipLaunchKernelGGL(k_tiles_to_frame, dim3((unsigned int)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)d_tiles,
-                     (unsigned int)k.W, (unsigned int)k.H, tile_stride, rank_pitch_bytes, elem_bytes, (unsigned char *)d_frame);
+  if (tiles_frame_pitch_bytes == 0) tiles_frame_pitch_bytes = shard;
+  if (frame_pitch_bytes == 0) frame_pitch_bytes = npix * elem_bytes;
+  if (rank_pitch_bytes == 0) rank_pitch_bytes = shard * n_frames;
+  const bool wide = elem_bytes % 4 == 0;
+  if (rank_pitch_bytes < tiles_frame_pitch_bytes * (n_frames - 1) + shard || tiles_frame_pitch_bytes < shard || frame_pitch_bytes < npix * elem_bytes ||
+      (wide && (rank_pitch_bytes % 8 || tiles_frame_pitch_bytes % 8 || frame_pitch_bytes % 8)))
+    return fail(RT_HIP_EINVAL, "rt_hip_tiles_to_frames_dev: a pitch is too small or misaligned");
+  hipLaunchKernelGGL(k_tiles_to_frame, dim3((unsigned int)((npix + 255) / 256), n_frames), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)d_tiles,
+                     (unsigned int)k.W, (unsigned int)k.H, tile_stride, rank_pitch_bytes, elem_bytes, (unsigned char *)d_frames, tiles_frame_pitch_bytes, frame_pitch_bytes);
   HIP_TRY(hipGetLastError());
   return RT_HIP_OK;
+}
+extern "C" int rt_hip_tiles_to_frame_dev(const rt_hip_camera *cam, uint32_t tile_stride, const void *d_tiles, uint64_t rank_pitch_bytes, uint32_t elem_bytes,
+                                         void *d_frame, void *stream)
+{
+  if (rank_pitch_bytes == 0) {              // tightly packed single frame
+    uint32_t total = 0, per_rank = 0;
+    int rc = rt_hip_tile_shard_info(cam, tile_stride ? tile_stride : 1, &total, &per_rank); if (rc) return rc;
+    rank_pitch_bytes = (uint64_t)per_rank * 8192 * elem_bytes;
+  }
+  return rt_hip_tiles_to_frames_dev(cam, tile_stride, d_tiles, rank_pitch_bytes, elem_bytes, 1, 0, d_frame, 0, stream);
 }
 
 // Camera.h:187-192 for the sample shard [s_first, s_first + s_count) of spp: sum of sample / spp into d_rgb

@@ -57,6 +57,19 @@ def test_tile_shards_reassemble(ctx, depth, stride):
         # the numpy model of the layout (used by the CPU two-rank test) agrees with the device kernel
         host = parallel.tiles_to_frame_host(tiles.cpu().numpy().reshape(stride, per.value, 64, 128, 3), cam.width, cam.height, stride)
         assert np.array_equal(host.reshape(-1, 3), frame)
+        # rt_hip_tiles_to_frames_dev: three frames per rank in one gather buffer (the second one is the real frame), one launch
+        blk = shards[0].numel() * shards[0].element_size()
+        batch = torch.zeros(stride * 3 * blk, dtype=torch.uint8, device="cuda")
+        for r in range(stride):
+            batch[(r * 3 + 1) * blk:(r * 3 + 2) * blk] = shards[r].view(torch.uint8).reshape(-1)
+        elem = 3 if bgr8 else 24
+        outs = torch.full((3, cam.width * cam.height * elem + 8), 7, dtype=torch.uint8, device="cuda")
+        rta.check(rta.hip.rt_hip_tiles_to_frames_dev(cam.raw, stride, C.c_void_p(batch.data_ptr()), 3 * blk, elem, 3, blk, C.c_void_p(outs.data_ptr()),
+                                                     outs.shape[1], None))
+        torch.cuda.synchronize()
+        got = outs[1, :cam.width * cam.height * elem].cpu().numpy()
+        assert np.array_equal(got.view(np.uint8 if bgr8 else np.float64).reshape(-1, 3), frame)
+        assert (outs[:, -8:] == 7).all() and (outs[0, :64] == 0).all()            # pitches respected; frame 0 was made of the zero tiles
     _full_frame(rta, ctx, g, cam)
     a, b = C.c_uint64(), C.c_uint64()
     rta.check(rta.hip.rt_hip_last_ray_count(g.device(ctx), C.byref(a), C.byref(b)))
