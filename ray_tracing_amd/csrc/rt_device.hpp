@@ -203,19 +203,23 @@ __device__ __forceinline__ double safe_inv(double x) { return (fabs(x) < 1e-30) 
 // about 3 ulp of s, divided by |d.n|), the point P' by the same amount, beta'/gamma' by that times |B|,|G|.
 // tmargin = 1e-6 s and mscale = 1e-8 s are > 10x those bounds; they also cover the reference's own rounding
 // noise in beta/gamma (~5e-11 |S| |B| / |d.n|).
-__device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_scale)
+// the part of the setup that depends on the origin only (the wave-wide scale of the margins): a light's shadow rays share it
+__device__ __forceinline__ double ray_origin_scale(V3 o, double coord_scale)
+{
+  double os = dmax(dmax(fabs(o.x), fabs(o.y)), fabs(o.z));
+  // one scale for the whole wave (the largest): in the redistributed cull a lane tests records for another lane's ray
+  for (int off = 32; off > 0; off >>= 1) os = dmax(os, __shfl_xor(os, off, 64));
+  { const unsigned long long b = __double_as_longlong(os);
+    os = __longlong_as_double(((unsigned long long)(unsigned)uni((int)(b >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned)b)); }
+  return 1.0 + coord_scale + os;
+}
+__device__ __forceinline__ void ray_setup_scaled(RayState &r, V3 o, V3 d, double s)
 {
   r.o = o; r.d = d;
   r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   r.oi = mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
   r.bound = kMiss; r.best_t = kMiss; r.best_id = -1;
   r.best_u = kInfty; r.best_v = kInfty; r.mb_id = -1; r.mb_t = kMiss; r.mb_u = kInfty; r.mb_v = kInfty;
-  double os = dmax(dmax(fabs(o.x), fabs(o.y)), fabs(o.z));
-  // one scale for the whole wave (the largest): in the redistributed cull a lane tests records for another lane's ray
-  for (int off = 32; off > 0; off >>= 1) os = dmax(os, __shfl_xor(os, off, 64));
-  { const unsigned long long b = __double_as_longlong(os);
-    os = __longlong_as_double(((unsigned long long)(unsigned)uni((int)(b >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned)b)); }
-  double s = 1.0 + coord_scale + os;
   r.tmargin = 1e-6 * s;
   r.mscale = 1e-8 * s;
   r.gmin = 1e-6;
@@ -223,6 +227,10 @@ __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_
   // over |d.n|: 16 ulp(s) / |d.n| bounds it, and keeps a ray's own triangle (t' ~ 1e-15) out of the survivors
   r.tlow = 16.0 * 2.3e-16 * s;
   r.dsign = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
+}
+__device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_scale)
+{
+  ray_setup_scaled(r, o, d, ray_origin_scale(o, coord_scale));
 }
 
 // A DPair through the scalar data path: the index is wave-uniform, so the 128 bytes arrive as two
@@ -1104,6 +1112,7 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
   const V3 O = mk(lp.x - sn * rr, lp.y - sn * rr, lp.z);
   const double per = area ? L.lum_per_sample : L.lum;
   double lum = 0;
+  const double scale = ray_origin_scale(pt, sc.coord_scale);      // every shadow ray of this point starts at pt
   for (int s = 0; s < sn * sn; s++) {
     const int i = s / sn, j = s % sn;
     V3 dir;
@@ -1113,7 +1122,7 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
       double ry = ref_random(rr, 1000, key.seed, key.pixel, key.sample, key.path, (uint32_t)li, (uint32_t)s, 1);
       dir = mk(x0 + rx, y0 + ry, z0) - pt;
     } else dir = (type == 100) ? (lp - pt) : neg(lp);
-    RayState r; ray_setup(r, pt, unitize(dir), sc.coord_scale);
+    RayState r; ray_setup_scaled(r, pt, unitize(dir), scale);
     // hits beyond the projection of the light position onto the ray can never satisfy the predicate
     const double t_limit = (type == 101) ? kMiss : fabs(dot(lp - pt, r.d)) + 1e-6 * (1.0 + sc.coord_scale);
     if (STATS && active) { st.rays++; st.shadow_rays++; }
