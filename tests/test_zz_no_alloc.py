@@ -56,3 +56,29 @@ def test_noalloc_refuses_what_does_not_fit(ctx):
     deep = rta.Camera(**dict(scenes.C1_CAMERA, depth=3))
     rc = rta.hip.rt_hip_render_whitted_noalloc(g.device(ctx), deep.raw, p, C.c_void_p(8), None, None)
     assert rc == -4 and b"depth" in rta.hip.rt_hip_last_error()
+
+
+def test_noalloc_call_replays_from_a_hip_graph(ctx):
+    """what the entry point is for: recorded into a HIP graph (stream capture forbids hipMalloc) and replayed, bit-identical to the direct call"""
+    import torch
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(light="point_area", gpu=True, oracle=False)
+    cam = rta.Camera(**scenes.C1_CAMERA)
+    n = cam.width * cam.height
+    p = rta.Params(background=(200, 200, 200), seed=3)
+    ref = torch.zeros(n * 3, dtype=torch.float64, device="cuda"); ref_ids = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rta.check(rta.hip.rt_hip_render_whitted_dev(g.device(ctx), cam.raw, p, C.c_void_p(ref.data_ptr()), C.c_void_p(ref_ids.data_ptr()), None))
+    torch.cuda.synchronize()
+    rgb = torch.full((n * 3,), -1.0, dtype=torch.float64, device="cuda"); ids = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        rc = rta.hip.rt_hip_render_whitted_noalloc(g.device(ctx), cam.raw, p, C.c_void_p(rgb.data_ptr()), C.c_void_p(ids.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rta.hip.rt_hip_last_error()
+    assert (ids == -7).all()                       # recording runs nothing
+    for rep in range(3):
+        rgb.fill_(-1.0); ids.fill_(-7)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ids, ref_ids) and torch.equal(rgb, ref)
