@@ -38,10 +38,13 @@ struct alignas(128) DPair {
   ChildRef l, r;
   int32_t axis, pad[3];
 };
+// The same pair as the device walks it: FP32 boxes rounded outward, 64 B = one s_load_dwordx16.  The split axis of a pair travels in the
+// i1 of the ChildRef that points at it.
+struct alignas(64) DPairF { float lmin[3], lmax[3], rmin[3], rmax[3]; ChildRef l, r; };
 
 // Leaf stream: a 64-byte header followed by `count` 128-byte records, contiguous, so that a wave can
 // pull a leaf into LDS with 16-byte-per-lane direct-to-LDS loads (1 KiB per instruction).
-struct alignas(64) LeafHeader { double bmin[3], bmax[3]; int32_t count, pad[3]; };
+struct alignas(64) LeafHeader { float bmin[3], bmax[3]; int32_t count, pad[9]; };   // box in FP32, rounded outward
 
 // One object reference of a leaf, 128 B (a triangle referenced by k leaves is stored k times).
 //   n (= m_norm), dpl = dot(v0,n)  -> t' = (dpl - o.n)/(d.n)
@@ -59,7 +62,7 @@ struct alignas(64) LeafRec {
   int32_t tri_idx, pad0;
   double pad1;
 };
-static_assert(sizeof(DPair) == 128 && sizeof(LeafHeader) == 64 && sizeof(LeafRec) == 128, "layout");
+static_assert(sizeof(DPair) == 128 && sizeof(DPairF) == 64 && sizeof(LeafHeader) == 64 && sizeof(LeafRec) == 128, "layout");
 
 #define RT_CHUNK_RECS 31                 // 64 + 31*128 = 4032 bytes, staged as 4 x 1 KiB
 #define RT_CHUNK_BYTES 4096
@@ -74,7 +77,7 @@ struct DLight { int32_t type, sample_num; double p[3], lum, len, lum_per_sample;
 struct DTexture { const uint8_t *bgr; int32_t rows, cols; };           // cv::Mat CV_8UC3: bgr[(row * cols + col) * 3 + {B,G,R}]
 
 struct DevScene {
-  const DPair *pairs; const unsigned char *leaf_stream;
+  const DPairF *pairs; const unsigned char *leaf_stream;
   ChildRef root; int32_t has_tree;              // has_tree == 0: CScene::FirstInterPt over all objects
   const int32_t *root_objs; int32_t n_root_objs;// bspTree.root->objects (infinite objects)
   const TriExact *tri_exact; const TriShade *tri_shade;   // tri_shade == NULL: no triangle has vertex normals
@@ -191,6 +194,9 @@ struct RayState {
   double gmin;        // per-ray |d.n| threshold below which the cull is not trusted
   double tlow;        // scale of the margin of the t > eps test: tlow / |d.n|
   unsigned dsign;     // bit a set: d[a] >= 0 (near-child order of the packet, never results)
+  // the FP32 form of the slab test (slab_f): inv per axis, and o * inv moved by the axis' error bound towards "earlier" for the plane the
+  // ray enters through (fa* pairs with bmin when inv >= 0) and "later" for the one it leaves through
+  float fix, fiy, fiz, fax, fay, faz, fbx, fby, fbz;
   double best_u, best_v;            // surface parameters of the confirmed hit (PARAM kernels only)
   int mb_id; double mb_t, mb_u, mb_v; // the last non-triangle leaf object tested and its result: the reference re-solves an
                                       // object in every leaf that lists it (Scene.h:352), always with the same result
@@ -213,6 +219,21 @@ __device__ __forceinline__ double ray_origin_scale(V3 o, double coord_scale)
     os = __longlong_as_double(((unsigned long long)(unsigned)uni((int)(b >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned)b)); }
   return 1.0 + coord_scale + os;
 }
+// One axis of the FP32 slab test.  slab() accepts a box on t64 = fma(b, inv, -oi) per plane; slab_f computes tf = fmaf(bf, (float)inv,
+// -(float)oi -+ E) with bf = b rounded outward.  With u = 2^-24: |tf - t64| <= (4 |b inv| + 2 |oi|) u (1 + ...) from the three roundings
+// to FP32 and the FMA's own, so E = 8 u (S |inv| + |oi|), S >= |b|, keeps the entry plane's tf <= t64 and the exit plane's tf >= t64 with the
+// rounding of oi -+ E (<= u |oi|) paid from the same margin: every box slab() accepts, slab_f accepts.  An axis whose FP32 products could
+// overflow is taken out of the test (NaN: v_min / v_max return the other operand), which only accepts more.
+__device__ __forceinline__ bool slab_axis_f(double inv, double oi, float Sf, float &fi, float &fa, float &fb)
+{
+  fi = (float)inv; const float fo = (float)oi;
+  const float E = 0x1p-21f * fmaf(Sf, fabsf(fi), fabsf(fo));
+  const bool ok = (Sf * fabsf(fi) < 1e37f) && (fabsf(fo) < 1e37f);
+  const float early = fo + E, late = fo - E;
+  fa = ok ? ((fi >= 0.0f) ? early : late) : __builtin_nanf("");
+  fb = ok ? ((fi >= 0.0f) ? late : early) : __builtin_nanf("");
+  return ok;
+}
 __device__ __forceinline__ void ray_setup_scaled(RayState &r, V3 o, V3 d, double s)
 {
   r.o = o; r.d = d;
@@ -227,6 +248,12 @@ __device__ __forceinline__ void ray_setup_scaled(RayState &r, V3 o, V3 d, double
   // over |d.n|: 16 ulp(s) / |d.n| bounds it, and keeps a ray's own triangle (t' ~ 1e-15) out of the survivors
   r.tlow = 16.0 * 2.3e-16 * s;
   r.dsign = (d.x >= 0.0 ? 1u : 0u) | (d.y >= 0.0 ? 2u : 0u) | (d.z >= 0.0 ? 4u : 0u);
+  // s >= 1 + max |box coordinate| (coord_scale covers the root box, which contains every node and leaf box)
+  const float Sf = (float)s * 1.000001f;
+  const bool kx = slab_axis_f(r.inv.x, r.oi.x, Sf, r.fix, r.fax, r.fbx);
+  const bool ky = slab_axis_f(r.inv.y, r.oi.y, Sf, r.fiy, r.fay, r.fby);
+  const bool kz = slab_axis_f(r.inv.z, r.oi.z, Sf, r.fiz, r.faz, r.fbz);
+  if (!(kx | ky | kz)) { r.fix = 0.0f; r.fax = __builtin_inff(); r.fbx = -__builtin_inff(); }   // nothing usable in FP32: every box passes
 }
 __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_scale)
 {
@@ -236,8 +263,8 @@ __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_
 // A DPair through the scalar data path: the index is wave-uniform, so the 128 bytes arrive as two
 // s_load_dwordx16 in SGPRs with ONE wait, and the slab tests take the box as scalar operands.
 // (Left to the compiler, the pair came in through five dependent vector-memory round trips.)
-typedef const __attribute__((address_space(4))) DPair *PairScalarPtr;
-__device__ __forceinline__ DPair load_pair(const DPair *pairs, int i)
+typedef const __attribute__((address_space(4))) DPairF *PairScalarPtr;
+__device__ __forceinline__ DPairF load_pair(const DPairF *pairs, int i)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
   return *(PairScalarPtr)(unsigned long long)(pairs + i);
@@ -258,6 +285,21 @@ __device__ __forceinline__ bool slab(const RayState &r, const double *bmin, cons
   t1 = fma(bmin[2], r.inv.z, -r.oi.z); t2 = fma(bmax[2], r.inv.z, -r.oi.z);
   tmin = fmax(tmin, fmin(t1, t2)); tmax = fmin(tmax, fmax(t1, t2));
   return (tmin <= tmax) && (tmax > 0.0) && (tmin <= r.bound);
+}
+
+// The walk's form of it in FP32 (half the issue cycles, a third of the registers): accepts every box slab() accepts (slab_axis_f), and a
+// little more -- boxes within ~1e-6 of the ray.  Visiting a box the ray misses changes nothing but the time.  bound_f >= the ray's bound.
+__device__ __forceinline__ float bound_up_f(double bound) { const float f = (float)bound; return fmaf(fabsf(f), 0x1p-22f, f); }
+__device__ __forceinline__ bool slab_f(const RayState &r, float bound_f, const float *bmin, const float *bmax)
+{
+  float t1 = fmaf(bmin[0], r.fix, -r.fax), t2 = fmaf(bmax[0], r.fix, -r.fbx);
+  const float lx = __builtin_fminf(t1, t2), hx = __builtin_fmaxf(t1, t2);
+  t1 = fmaf(bmin[1], r.fiy, -r.fay); t2 = fmaf(bmax[1], r.fiy, -r.fby);
+  const float ly = __builtin_fminf(t1, t2), hy = __builtin_fmaxf(t1, t2);
+  t1 = fmaf(bmin[2], r.fiz, -r.faz); t2 = fmaf(bmax[2], r.fiz, -r.fbz);
+  const float lz = __builtin_fminf(t1, t2), hz = __builtin_fmaxf(t1, t2);
+  const float tmin = __builtin_fmaxf(__builtin_fmaxf(lx, ly), lz), tmax = __builtin_fminf(__builtin_fminf(hx, hy), hz);
+  return (tmin <= tmax) && (tmax >= 0.0f) && (tmin <= bound_f);
 }
 
 // can a Newton-solved object still matter to this ray?  Its accepted hits lie in [pmin, pmax] (rt_param.hpp: param_prune_box), in front of
@@ -453,12 +495,13 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
     RT_TM(0)
     if (i0 >= 0) {
       // ---- inner node: fetch both child boxes at once, keep the children some lane wants ----
-      const DPair P = load_pair(sc.pairs, i0);
-      const bool wl = slab(r, P.lmin, P.lmax) & live;
-      const bool wr = slab(r, P.rmin, P.rmax) & live;
+      const DPairF P = load_pair(sc.pairs, i0);
+      const float bound_f = bound_up_f(r.bound);
+      const bool wl = slab_f(r, bound_f, P.lmin, P.lmax) & live;
+      const bool wr = slab_f(r, bound_f, P.rmin, P.rmax) & live;
       if (STATS) { if (live) st.node_visits += 2; if ((threadIdx.x & 63) == 0) st.wave_nodes += 2; }
       const unsigned long long ml = __ballot(wl), mr = __ballot(wr);
-      const unsigned long long pos = __ballot((wl | wr) & (((r.dsign >> P.axis) & 1u) != 0u));
+      const unsigned long long pos = __ballot((wl | wr) & (((r.dsign >> i1) & 1u) != 0u));
       const bool left_first = (2 * __popcll(pos) >= __popcll(ml | mr));
       // continue with the near child; the far one waits on the stack
       if (ml != 0ull && mr != 0ull) {
@@ -493,7 +536,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
         RT_TM(2) RT_TM_CNT(6)
         if (c0 == 0) {
           const LeafHeader *H = (const LeafHeader *)lds->leaf;
-          want = live && slab(r, H->bmin, H->bmax);
+          want = live && slab_f(r, bound_up_f(r.bound), H->bmin, H->bmax);
           if (STATS) { if (live) st.node_visits++; if ((threadIdx.x & 63) == 0) st.wave_nodes++; }
           if (__ballot(want) == 0ull) break;
         }

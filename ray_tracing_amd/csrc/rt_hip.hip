@@ -230,6 +230,9 @@ struct Builder {
     return c;
   }
 
+  // FP32 box coordinates, rounded away from the box's inside
+  static float f32_down(double x) { float f = (float)x; return ((double)f > x) ? std::nextafterf(f, -INFINITY) : f; }
+  static float f32_up(double x) { float f = (float)x; return ((double)f < x) ? std::nextafterf(f, INFINITY) : f; }
   // emits a leaf for the object list `objs` in kd cell `cell`
   Sub emit_leaf(const std::vector<uint32_t> &objs, const Box &cell, uint32_t depth)
   {
@@ -242,9 +245,9 @@ struct Builder {
     LeafHeader H; std::memset(&H, 0, sizeof H);
     for (int a = 0; a < 3; a++) {
       // every hit point of a referenced object inside this cell lies in cell /\ union(AABB)
-      H.bmin[a] = std::max(cell.mn[a], u.mn[a]) - kBoxPad;
-      H.bmax[a] = std::min(cell.mx[a], u.mx[a]) + kBoxPad;
-      out.box.mn[a] = H.bmin[a]; out.box.mx[a] = H.bmax[a];
+      out.box.mn[a] = std::max(cell.mn[a], u.mn[a]) - kBoxPad;
+      out.box.mx[a] = std::min(cell.mx[a], u.mx[a]) + kBoxPad;
+      H.bmin[a] = f32_down(out.box.mn[a]); H.bmax[a] = f32_up(out.box.mx[a]);
     }
     H.count = (int32_t)objs.size();
     size_t off = stream.size();
@@ -269,7 +272,7 @@ struct Builder {
     for (int a = 0; a < 3; a++) { P.lmin[a] = l.box.mn[a]; P.lmax[a] = l.box.mx[a]; P.rmin[a] = r.box.mn[a]; P.rmax[a] = r.box.mx[a]; }
     P.l = l.ref; P.r = r.ref; P.axis = axis;
     pairs[slot] = P;
-    Sub out; out.empty = false; out.ref = ChildRef{slot, 0};
+    Sub out; out.empty = false; out.ref = ChildRef{slot, axis};
     for (int a = 0; a < 3; a++) { out.box.mn[a] = std::min(l.box.mn[a], r.box.mn[a]); out.box.mx[a] = std::max(l.box.mx[a], r.box.mx[a]); }
     max_depth = std::max(max_depth, depth);
     return out;
@@ -1248,7 +1251,7 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
     if (root.empty) {
       // a tree without finite content: one empty leaf keeps the "has tree" semantics (Scene.h:87)
       LeafHeader H; std::memset(&H, 0, sizeof H);
-      for (int a = 0; a < 3; a++) { H.bmin[a] = 1e300; H.bmax[a] = -1e300; }
+      for (int a = 0; a < 3; a++) { H.bmin[a] = 3e38f; H.bmax[a] = -3e38f; }
       size_t off = B.stream.size(); B.stream.resize(off + 64); std::memcpy(&B.stream[off], &H, 64);
       root_ref = ChildRef{-1, (int32_t)(off / 64)};
     } else {
@@ -1316,7 +1319,20 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
       up(upload(s, tuv, &D.tri_uv));
     }
   }
-  up(upload(s, B.pairs, &D.pairs)); up(upload(s, B.stream, &D.leaf_stream));
+  {
+    // the walk's pairs: FP32 boxes rounded outward (the FP64 ones stay the builder's)
+    std::vector<DPairF> pf(B.pairs.size());
+    for (size_t i = 0; i < pf.size(); i++) {
+      const DPair &P = B.pairs[i];
+      for (int a = 0; a < 3; a++) {
+        pf[i].lmin[a] = Builder::f32_down(P.lmin[a]); pf[i].lmax[a] = Builder::f32_up(P.lmax[a]);
+        pf[i].rmin[a] = Builder::f32_down(P.rmin[a]); pf[i].rmax[a] = Builder::f32_up(P.rmax[a]);
+      }
+      pf[i].l = P.l; pf[i].r = P.r;
+    }
+    up(upload(s, pf, &D.pairs));
+  }
+  up(upload(s, B.stream, &D.leaf_stream));
   up(upload(s, root_objs, &D.root_objs)); up(upload(s, B.tri_exact, &D.tri_exact));
   {
     // vertex normals only where a mesh has them (Object.h:448-457): a flat-shaded scene keeps 80 bytes per triangle out of HBM
