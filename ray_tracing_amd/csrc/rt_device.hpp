@@ -84,7 +84,6 @@ struct DevScene {
   const DPlane *planes; const DSphere *spheres; const DCircle *circles;
   const DBezier *beziers; const DRotational *rotationals;
   int32_t has_param;                            // the scene holds Bezier / rotational objects: kernels built with PARAM
-  int32_t prefetch_leaves;                      // the leaf stream is larger than the L2s: touch far leaves ahead of their staging
   const uint8_t *obj_type; const uint32_t *obj_index; const uint32_t *obj_mat; const double *obj_colour;
   int32_t n_objects;
   // textures (Object.h:69-74); obj_tex == NULL: no object of the scene has one
@@ -433,7 +432,7 @@ struct Deferred {
 // ANY = false: closest hit; confirmed hits go to r.best_t / r.best_id, r.bound prunes.
 // ANY = true : occlusion; `found` becomes true for a lane as soon as a confirmed hit satisfies occludes()
 //              (DEFER: as soon as a cull survivor MAY satisfy it; D.c1_id remembers which).
-template <bool ANY, bool DEFER, bool STATS, bool PARAM, bool PF = false>
+template <bool ANY, bool DEFER, bool STATS, bool PARAM>
 __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref, double fmargin,
                                      WaveLds *lds, Stats &st, Deferred &D, bool &found, bool record)
 {
@@ -480,7 +479,6 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
   // the node stack: entry k lives in lane k of these two registers (the entries are wave-uniform, the depth is at most RT_STACK_DEPTH = 64):
   // v_writelane / v_readlane instead of an LDS round trip per push and pop (measured +1.7 % on C2)
   int stk0 = 0, stk1 = 0;
-  unsigned int pf_val = 0, pf_acc = 0;           // PF: far leaves touched ahead of their staging (kernels of large scenes)
   RT_TM_DECL
   while (true) {
     if (!have) {
@@ -512,17 +510,6 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
       }
       else if (ml != 0ull) { cur = P.l; have = true; }
       else if (mr != 0ull) { cur = P.r; have = true; }
-      // the far child waits on the stack; if it is a leaf, touch its lines now (one dword per 64-B line, 64 lanes = the
-      // 4 KiB a leaf chunk spans) so that its staging later finds them in L2.  The value is consumed after the next
-      // staging wait (below), never earlier.
-      if (PF && sc.prefetch_leaves && ml != 0ull && mr != 0ull) {
-        const ChildRef far = left_first ? P.r : P.l;
-        if (far.i0 < 0) {
-          const unsigned char *fb = sc.leaf_stream + (size_t)(unsigned)far.i1 * 64;
-          pf_val = *(const unsigned int *)(fb + (threadIdx.x & 63) * 64);
-        }
-        // (the same for an inner far child -- touching its pair's two lines -- came out 1 % slower)
-      }
       RT_TM(1) RT_TM_CNT(5)
     } else {
       // ---- leaf: stage header + records in LDS chunk by chunk ----
@@ -532,7 +519,6 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
       for (int c0 = 0; c0 < cnt; c0 += RT_CHUNK_RECS) {
         const int nrec = (cnt - c0 < RT_CHUNK_RECS) ? (cnt - c0) : RT_CHUNK_RECS;
         stage_chunk(base + (size_t)c0 * sizeof(LeafRec), lds->leaf, 64 + nrec * (int)sizeof(LeafRec));
-        if (PF) pf_acc ^= pf_val;
         RT_TM(2) RT_TM_CNT(6)
         if (c0 == 0) {
           const LeafHeader *H = (const LeafHeader *)lds->leaf;
@@ -734,14 +720,13 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
       }
     }
   }
-  if (PF) { pf_acc ^= pf_val; asm volatile("" :: "v"(pf_acc)); }
   solve_pairs(1);
   RT_TM_FLUSH
 }
 
 // Closest hit of one ray per lane (CScene::FirstInterPt_BSPTree, Scene.h:85-91; FirstInterPt, Scene.h:62-83,
 // when the scene has no tree).  Result in r.best_t / r.best_id.  All lanes of the wave call this together.
-template <bool STATS, bool PARAM, bool PF = false>
+template <bool STATS, bool PARAM>
 __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, bool active, WaveLds *lds, Stats &st, bool record = true)
 {
   auto take = [&](double t, int id, double hu = kInfty, double hv = kInfty) {   // the update rule of Scene.h:74-79 (objects come in id order)
@@ -804,7 +789,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
   if (inf_id >= 0) r.bound = inf_t + r.tmargin;
   Deferred D; D.c1_t = D.c2_t = D.c3_t = kMiss; D.c1_id = D.c2_id = -1; D.redo = false;
   bool dummy = false;
-  walk<false, true, STATS, PARAM, PF>(sc, r, active, false, mk(0, 0, 0), 0.0, lds, st, D, dummy, record);
+  walk<false, true, STATS, PARAM>(sc, r, active, false, mk(0, 0, 0), 0.0, lds, st, D, dummy, record);
   // ---- confirm the survivors, all lanes together ----
   const bool h1 = active && D.c1_id >= 0, h2 = active && D.c2_id >= 0;
   double t1 = kMiss, t2 = kMiss;
@@ -842,7 +827,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
 // Occlusion query of one ray per lane: is there a hit X with occludes() true (Scene.h:449, Light.h:66,91,147)?
 // t_limit: no hit beyond it can satisfy the predicate (kMiss if unbounded).  Shadow tests go through
 // FirstInterPt_Unrecorded (Light.h:65, 90, 146; Scene.h:448 record = false).
-template <bool STATS, bool PARAM, bool PF = false>
+template <bool STATS, bool PARAM>
 __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref, double t_limit,
                                                WaveLds *lds, Stats &st)
 {
@@ -904,7 +889,7 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
   const double fmargin = 3.0 * (len(ref - r.o) + 1.0) * r.tmargin;
   Deferred D; D.c1_t = D.c2_t = D.c3_t = kMiss; D.c1_id = D.c2_id = -1; D.redo = false;
   const bool pre = found;
-  walk<true, true, STATS, PARAM, PF>(sc, r, active && !pre, has_ref, ref, fmargin, lds, st, D, found, false);
+  walk<true, true, STATS, PARAM>(sc, r, active && !pre, has_ref, ref, fmargin, lds, st, D, found, false);
   // ---- confirm the survivor that stopped the walk ----
   const bool h1 = active && !pre && found && D.c1_id >= 0;
   bool ok = false;
@@ -1143,7 +1128,7 @@ struct RngKey { uint64_t seed; uint32_t pixel, sample, path; };
 // Light.h:62-69 / 87-94, CAreaLight::luminosity (Light.h:126-162) and luminosity_BSPTree
 // (Scene.h:436-455).  Every shadow query is a wave-packet occlusion walk; point and parallel lights are
 // the one-sample case of the same loop.
-template <bool STATS, bool PARAM, bool PF = false, bool ONE = false>
+template <bool STATS, bool PARAM, bool ONE = false>
 __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLight &L, int li, V3 pt, bool active,
                                                    const RngKey &key, WaveLds *lds, Stats &st)
 {
@@ -1169,7 +1154,7 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
     // hits beyond the projection of the light position onto the ray can never satisfy the predicate
     const double t_limit = (type == 101) ? kMiss : fabs(dot(lp - pt, r.d)) + 1e-6 * (1.0 + sc.coord_scale);
     if (STATS && active) { st.rays++; st.shadow_rays++; }
-    bool occ = trace_occluded<STATS, PARAM, PF>(sc, r, active, type != 101, lp, t_limit, lds, st);
+    bool occ = trace_occluded<STATS, PARAM>(sc, r, active, type != 101, lp, t_limit, lds, st);
     if (!occ) lum += per;
   }
   return lum;

@@ -802,7 +802,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
     V3 o, d; camera_ray(o, d);
     RayState r; ray_setup(r, o, d, sc.coord_scale);
     if (STATS && active) st.rays++;
-    trace_closest<STATS, PARAM, true>(sc, r, active, stack, st);
+    trace_closest<STATS, PARAM>(sc, r, active, stack, st);
     id = r.best_id; t = r.best_t;
     if (PARAM) { hu = r.best_u; hv = r.best_v; }
     pt = o + d * t;
@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   for (int li = 0; li < nl; li++) {
     const DLight &L = sc.lights[li];
     RngKey key; key.seed = A.seed; key.pixel = pix; key.sample = A.sample_first + s_local; key.path = 1;
-    double l = light_luminosity<STATS, PARAM, true, ONE>(sc, L, li, pt, hit, key, stack, st);
+    double l = light_luminosity<STATS, PARAM, ONE>(sc, L, li, pt, hit, key, stack, st);
     if (ONE) l_one = l;
     else if (hit) lum[((size_t)wave * 64 + lane) * nl + li] = l;
   }
@@ -1345,7 +1345,6 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   up(upload(s, planes, &D.planes)); up(upload(s, spheres, &D.spheres)); up(upload(s, circles, &D.circles));
   up(upload(s, beziers, &D.beziers)); up(upload(s, rots, &D.rotationals));
   D.has_param = (d->n_beziers || d->n_rotationals) ? 1 : 0;
-  D.prefetch_leaves = (B.stream.size() > (32u << 20)) ? 1 : 0;       // 8 XCDs x 4 MiB of L2: smaller scenes stay resident anyway
   up(upload(s, types, &D.obj_type)); up(upload(s, index, &D.obj_index)); up(upload(s, omat, &D.obj_mat));
   up(upload(s, colour, &D.obj_colour)); up(upload(s, mats, &D.materials)); up(upload(s, lights, &D.lights));
   if (rc != RT_HIP_OK) { std::string m = g_err; rt_hip_scene_destroy(s); return fail(rc, m); }
