@@ -192,7 +192,8 @@ int rt_hip_get_stats(rt_hip_ctx *ctx, rt_hip_stats *out, int reset);
  * in Scene.h:349-387, and every hit is confirmed with the reference's arithmetic.  leaf_refine selects:
  *   RT_HIP_LEAF_REFINE_DEFAULT      the library's own hierarchy over the finite objects: an object partition
  *                                   (every object in one leaf, child boxes = bounds of their objects, cuts chosen
- *                                   by a surface-area cost), tuned leaf size;
+ *                                   by a surface-area cost), tuned leaf size (leaves of fewer than 20 objects,
+ *                                   fewer than 8 in scenes of at most 1024 objects);
  *   RT_HIP_LEAF_REFINE_NONE         the reference's tree exactly as described (leaves < 100 objects, BSPTree.h:56-60);
  *   n (2 ...)                       the reference's tree, its leaves split further down to fewer than n objects;
  *   RT_HIP_LEAF_REFINE_OWN | n      the library's own hierarchy with leaves of fewer than n objects.

@@ -129,7 +129,12 @@ __device__ __forceinline__ unsigned int level_count(const unsigned int *n_dev, u
 // scene preparation (host)
 // ================================================================================================
 namespace {
-constexpr uint32_t kOwnLeaf = 24;   // leaf size of the library's own hierarchy (C2 sweep: 16..28 within 1 %; 16, 32 or 64 cuts per axis make no difference either)
+// Leaf size of the library's own hierarchy (leaves hold fewer objects than this).  Sweeps of round 2 with the FP32 box tests: C2 (1 M
+// triangles) 12: -2 %, 16: 0, 18-20: +1.4 %, 24: 0, 32: -6 %, 62: -27 %; C4 (11.6 k objects) flat from 8 to 24; C3 (a 20-triangle solid, 100
+// shadow rays per sample: the records culled per ray are what its time goes into) 4: +28 %, 6-8: +33 %, 12: +25 %, 20: +13 % against 24.
+// A node step on a scene whose pairs stay in the scalar cache is cheap, on a large one it is a memory round trip: small scenes get small leaves.
+constexpr uint32_t kOwnLeaf = 20, kOwnLeafSmall = 8, kSmallScene = 1024;
+static uint32_t own_leaf_default(uint32_t n_objects) { return n_objects <= kSmallScene ? kOwnLeafSmall : kOwnLeaf; }
 
 struct Box { double mn[3], mx[3]; };
 
@@ -1225,8 +1230,8 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   // rt_hip.h: DEFAULT = the library's own hierarchy with its tuned leaf size; NONE = the reference's tree as described;
   // n = the reference's tree with its leaves split down to n objects; RT_HIP_LEAF_REFINE_OWN | n = own hierarchy, leaf size n
   const bool own_tree = (leaf_refine == RT_HIP_LEAF_REFINE_DEFAULT) || (leaf_refine != RT_HIP_LEAF_REFINE_NONE && (leaf_refine & RT_HIP_LEAF_REFINE_OWN));
-  B.leaf_refine = (leaf_refine == RT_HIP_LEAF_REFINE_DEFAULT) ? kOwnLeaf : (leaf_refine == RT_HIP_LEAF_REFINE_NONE ? 0u : (leaf_refine & ~RT_HIP_LEAF_REFINE_OWN));
-  if (own_tree && B.leaf_refine < 2) B.leaf_refine = kOwnLeaf;
+  B.leaf_refine = (leaf_refine == RT_HIP_LEAF_REFINE_DEFAULT) ? own_leaf_default(d->n_objects) : (leaf_refine == RT_HIP_LEAF_REFINE_NONE ? 0u : (leaf_refine & ~RT_HIP_LEAF_REFINE_OWN));
+  if (own_tree && B.leaf_refine < 2) B.leaf_refine = own_leaf_default(d->n_objects);
   // triangles: m_norm = ((v1 - v0) ^ (v2 - v0)).Unitize(), Object.h:365
   B.tri_exact.resize(d->n_triangles);
   std::vector<TriShade> tri_shade(d->n_triangles);
