@@ -276,7 +276,7 @@ def bench_c2(args, D, torch, rta, W):
                       "ms_per_frame": round(ms_per_step / F, 4), "frames_in_flight": S,
                       "parallelism": ("one frame split over %d ranks by interleaved 128x64 super-tiles, %d-frame all-gather: %s" % (tw, G, comm_kind)) if tiles_mode
                                      else ("replicas x%d (no collective)" % world if world > 1 else "1 GPU"),
-                      "leaf_refine": "library default (own hierarchy, leaves < 20; < 8 for scenes of at most 1024 objects)" if args.leaf_refine is None else args.leaf_refine,
+                      "leaf_refine": "library default (own hierarchy, leaves < 20; < 8 for scenes of at most 4096 objects)" if args.leaf_refine is None else args.leaf_refine,
                       "scene_build_s": round(build_s, 2)}}
     if emulate:
         out["config"]["emulated"] = "rank 0's share of a %d-rank run on one GPU, no collective: value = this rank's rate x %d (a projection, not a result)" % (tw, tw)

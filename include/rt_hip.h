@@ -193,7 +193,7 @@ int rt_hip_get_stats(rt_hip_ctx *ctx, rt_hip_stats *out, int reset);
  *   RT_HIP_LEAF_REFINE_DEFAULT      the library's own hierarchy over the finite objects: an object partition
  *                                   (every object in one leaf, child boxes = bounds of their objects, cuts chosen
  *                                   by a surface-area cost), tuned leaf size (leaves of fewer than 20 objects,
- *                                   fewer than 8 in scenes of at most 1024 objects);
+ *                                   fewer than 8 in scenes of at most 4096 objects);
  *   RT_HIP_LEAF_REFINE_NONE         the reference's tree exactly as described (leaves < 100 objects, BSPTree.h:56-60);
  *   n (2 ...)                       the reference's tree, its leaves split further down to fewer than n objects;
  *   RT_HIP_LEAF_REFINE_OWN | n      the library's own hierarchy with leaves of fewer than n objects.

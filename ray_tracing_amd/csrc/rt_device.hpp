@@ -95,6 +95,7 @@ struct DevScene {
   double ambient;
   double coord_scale;                           // max |coordinate| of finite geometry
   double rbmin[3], rbmax[3];                    // root box (inflated); only used to order work, never for results
+  float rbf_min[3], rbf_max[3];                 // the same in FP32, rounded outward: shadow rays that miss it skip the walk (trace_occluded)
 };
 
 struct Stats { unsigned long long rays, shadow_rays, node_visits, prim_tests, exact_tests, wave_nodes, wave_prims, pad; };
@@ -827,7 +828,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
 // Occlusion query of one ray per lane: is there a hit X with occludes() true (Scene.h:449, Light.h:66,91,147)?
 // t_limit: no hit beyond it can satisfy the predicate (kMiss if unbounded).  Shadow tests go through
 // FirstInterPt_Unrecorded (Light.h:65, 90, 146; Scene.h:448 record = false).
-template <bool STATS, bool PARAM>
+template <bool STATS, bool PARAM, bool ROOT_TEST = true>
 __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref, double t_limit,
                                                WaveLds *lds, Stats &st)
 {
@@ -886,10 +887,15 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
     if (lane_on && t < kMiss && occludes(r.o, r.d, t, has_ref, ref)) found = true;
   }
   r.bound = t_limit;
+  const bool pre = found;
+  // every finite object lies in the root box: a ray that misses it (same conservative FP32 test as the node steps) has nothing to
+  // meet in the tree, and a wave of such rays -- most shadow rays of an open scene -- skips the walk and its set-up altogether
+  // (C3 +4 %, C4 +2 %; not in the one-light frame kernel, whose shadow rays start on the geometry inside the box: C2 -0.5 % with it)
+  const bool walk_on = active && !pre && (!ROOT_TEST || slab_f(r, bound_up_f(t_limit), sc.rbf_min, sc.rbf_max));
+  if (ROOT_TEST && __ballot(walk_on) == 0ull) return found;
   const double fmargin = 3.0 * (len(ref - r.o) + 1.0) * r.tmargin;
   Deferred D; D.c1_t = D.c2_t = D.c3_t = kMiss; D.c1_id = D.c2_id = -1; D.redo = false;
-  const bool pre = found;
-  walk<true, true, STATS, PARAM>(sc, r, active && !pre, has_ref, ref, fmargin, lds, st, D, found, false);
+  walk<true, true, STATS, PARAM>(sc, r, walk_on, has_ref, ref, fmargin, lds, st, D, found, false);
   // ---- confirm the survivor that stopped the walk ----
   const bool h1 = active && !pre && found && D.c1_id >= 0;
   bool ok = false;
@@ -1154,7 +1160,7 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
     // hits beyond the projection of the light position onto the ray can never satisfy the predicate
     const double t_limit = (type == 101) ? kMiss : fabs(dot(lp - pt, r.d)) + 1e-6 * (1.0 + sc.coord_scale);
     if (STATS && active) { st.rays++; st.shadow_rays++; }
-    bool occ = trace_occluded<STATS, PARAM>(sc, r, active, type != 101, lp, t_limit, lds, st);
+    bool occ = trace_occluded<STATS, PARAM, !ONE>(sc, r, active, type != 101, lp, t_limit, lds, st);
     if (!occ) lum += per;
   }
   return lum;

@@ -130,10 +130,10 @@ __device__ __forceinline__ unsigned int level_count(const unsigned int *n_dev, u
 // ================================================================================================
 namespace {
 // Leaf size of the library's own hierarchy (leaves hold fewer objects than this).  Sweeps of round 2 with the FP32 box tests: C2 (1 M
-// triangles) 12: -2 %, 16: 0, 18-20: +1.4 %, 24: 0, 32: -6 %, 62: -27 %; C4 (11.6 k objects) flat from 8 to 24; C3 (a 20-triangle solid, 100
+// triangles) 12: -2 %, 16: 0, 18-20: +1.4 %, 24: 0, 32: -6 %, 62: -27 %; C4 (11.6 k objects) flat from 8 to 24; C3 (a 1,369-triangle solid, 100
 // shadow rays per sample: the records culled per ray are what its time goes into) 4: +28 %, 6-8: +33 %, 12: +25 %, 20: +13 % against 24.
 // A node step on a scene whose pairs stay in the scalar cache is cheap, on a large one it is a memory round trip: small scenes get small leaves.
-constexpr uint32_t kOwnLeaf = 20, kOwnLeafSmall = 8, kSmallScene = 1024;
+constexpr uint32_t kOwnLeaf = 20, kOwnLeafSmall = 8, kSmallScene = 4096;
 static uint32_t own_leaf_default(uint32_t n_objects) { return n_objects <= kSmallScene ? kOwnLeafSmall : kOwnLeaf; }
 
 struct Box { double mn[3], mx[3]; };
@@ -1261,7 +1261,7 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
       root_ref = ChildRef{-1, (int32_t)(off / 64)};
     } else {
       root_ref = root.ref;
-      for (int a = 0; a < 3; a++) { s->dev.rbmin[a] = root.box.mn[a]; s->dev.rbmax[a] = root.box.mx[a]; }
+      for (int a = 0; a < 3; a++) { s->dev.rbmin[a] = root.box.mn[a]; s->dev.rbmax[a] = root.box.mx[a]; s->dev.rbf_min[a] = Builder::f32_down(root.box.mn[a]); s->dev.rbf_max[a] = Builder::f32_up(root.box.mx[a]); }
       for (int a = 0; a < 3; a++) cs = std::max(cs, std::max(std::fabs(root.box.mn[a]), std::fabs(root.box.mx[a])));
     }
     if (B.pairs.empty()) B.pairs.emplace_back();
