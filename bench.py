@@ -338,14 +338,14 @@ def bench_c2(args, D, torch, rta, W):
     nodes_per_ray, prims_per_ray, exact_per_ray = st["node_visits"] / nrays, st["prim_tests"] / nrays, st["exact_tests"] / nrays
     wave_boxes_per_ray, wave_recs_per_ray = st["wave_node_visits"] / nrays, st["wave_prim_tests"] / nrays
     # Algorithmic bytes, two definitions.  PACKET: a wave of 64 rays walks the tree together, so a
-    # box test's 64 B (half a 128-B child pair, or a leaf header) and a cull record's 128 B move once per WAVE that needs
+    # box test's 32 B (half a 64-B child pair of FP32 boxes; a leaf header, one box test in ten, is counted the same) and a cull record's 128 B move once per WAVE that needs
     # them; the 96-B exact triangle of a confirmation is per ray; the frame is 3 B per pixel = per two rays.  LANE: what 64
     # independent rays would fetch (SURVEY 8d's per-ray formula on this traversal's counts) -- served from LDS / SGPR
     # broadcasts, not from HBM.
     io_bytes = 1.5
-    bytes_per_ray = io_bytes + 64 * wave_boxes_per_ray + 128 * wave_recs_per_ray + 96 * exact_per_ray
-    lane_bytes_per_ray = io_bytes + 64 * nodes_per_ray + 128 * prims_per_ray + 96 * exact_per_ray
-    flops_per_ray = 40 * nodes_per_ray + 45 * prims_per_ray + 150 * exact_per_ray
+    bytes_per_ray = io_bytes + 32 * wave_boxes_per_ray + 128 * wave_recs_per_ray + 96 * exact_per_ray
+    lane_bytes_per_ray = io_bytes + 32 * nodes_per_ray + 128 * prims_per_ray + 96 * exact_per_ray
+    flops_per_ray = 45 * prims_per_ray + 150 * exact_per_ray      # FP64 only: the box tests (40 flop each) run in FP32
     ach_gbs = bytes_per_ray * rays_dom / (dom_ms * 1e-3) / 1e9
     tf = flops_per_ray * rays_dom / (dom_ms * 1e-3) / 1e12
     pmc = read_traffic(dom)
@@ -364,7 +364,7 @@ def bench_c2(args, D, torch, rta, W):
                 "kernel_ms": round(dom_ms, 4), "kernel_ms_source": "HIP events on the kernel's stream, one frame in flight, %d launches" % n_one,
                 "rays_per_launch": int(rays_dom), "valu_wave_insts_per_launch": valu_insts,
                 "valu_lane_insts_per_ray": round(valu_insts * 64.0 / rays_dom, 1) if valu_insts else None,
-                "note": "the walk is bound by VALU issue (FP64 cull / slab arithmetic + the integer work around it), not by HBM: the scene (0.2 GB) is L2 / "
+                "note": "the walk is bound by VALU issue (FP32 box tests, FP64 cull and confirmation + the integer work around them), not by HBM: the scene (0.2 GB) is L2 / "
                         "Infinity-Cache resident.  peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; SQ_INSTS_VALU from profiles/r02_traffic.json",
                 "hbm": {"achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4),
                         "bytes_per_ray": round(bytes_per_ray, 1), "bytes_definition": "packet: node / record bytes once per wave that needs them",
