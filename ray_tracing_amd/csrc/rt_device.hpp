@@ -1,11 +1,11 @@
 // rt_device.hpp -- device-side scene layout, wave-packet BSP traversal and shading for gfx950.
 //
 // Execution model (wave64): one ray per lane, 64 rays per wave walk the tree TOGETHER.  The node
-// stack is wave-uniform (8 bytes per entry, in LDS).  An inner step fetches the boxes of BOTH
-// children with scalar loads (one 128-byte DPair, wave-uniform address) and each lane slab-tests
-// its own ray; a child is pushed only if some lane wants it (__ballot), far child first according
+// stack is wave-uniform (8 bytes per entry, in the lanes of two VGPRs).  An inner step fetches the boxes of BOTH
+// children with one scalar load (a 64-byte DPairF of FP32 boxes, wave-uniform address) and each lane slab-tests
+// its own ray (in FP32, conservatively: slab_axis_f); a child is pushed only if some lane wants it (__ballot), far child first according
 // to the majority ray direction, so the walk is front-to-back for most lanes and every lane
-// prunes with its own best t.  A leaf is a contiguous stream (header + 192-byte records) that the
+// prunes with its own best t.  A leaf is a contiguous stream (header + 128-byte records) that the
 // wave pulls into LDS with direct-to-LDS loads (16 B per lane, all loads of a chunk in flight
 // together) and then reads back as broadcasts.
 //
@@ -30,7 +30,7 @@ namespace rt {
 // i0 < 0 -> leaf with (-1 - i0) records, i1 = offset of its stream in 64-byte units.
 struct ChildRef { int32_t i0, i1; };
 
-// The two children of one inner node, 128 B = one scalar-cache line pair: both boxes are fetched and
+// The two children of one inner node as the builder keeps them (FP64): both boxes are fetched and
 // tested in ONE step of the walk.  Boxes are tight (cell /\ bounds of the content) and inflated by kBoxPad.
 struct alignas(128) DPair {
   double lmin[3], lmax[3];
@@ -260,7 +260,7 @@ __device__ __forceinline__ void ray_setup(RayState &r, V3 o, V3 d, double coord_
   ray_setup_scaled(r, o, d, ray_origin_scale(o, coord_scale));
 }
 
-// A DPair through the scalar data path: the index is wave-uniform, so the 128 bytes arrive as two
+// A pair through the scalar data path: the index is wave-uniform, so the 64 bytes arrive as one
 // s_load_dwordx16 in SGPRs with ONE wait, and the slab tests take the box as scalar operands.
 // (Left to the compiler, the pair came in through five dependent vector-memory round trips.)
 typedef const __attribute__((address_space(4))) DPairF *PairScalarPtr;
