@@ -170,11 +170,11 @@ __device__ __forceinline__ bool occludes(V3 o, V3 d, double t, bool has_ref, V3 
 
 // Diagnostic build only (-DRT_TIMERS): shader-clock cycles per section of the walk, summed over waves.
 #ifdef RT_TIMERS
-__device__ unsigned long long g_timers[16];
-#define RT_TM_DECL unsigned long long tm_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_readcyclecounter();
+__device__ unsigned long long g_timers[32];     // [closest, occluded][0-4 cycles per section, 5-15 trip counts]
+#define RT_TM_DECL unsigned long long tm_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tm_t = __builtin_readcyclecounter();
 #define RT_TM(k) { unsigned long long tm_n = __builtin_readcyclecounter(); tm_[k] += tm_n - tm_t; tm_t = tm_n; }
 #define RT_TM_CNT(k) { tm_[k]++; }
-#define RT_TM_FLUSH { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_timers[k_ + (ANY ? 8 : 0)], tm_[k_]); }
+#define RT_TM_FLUSH { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 16; k_++) atomicAdd(&g_timers[k_ + (ANY ? 16 : 0)], tm_[k_]); }
 #else
 #define RT_TM_DECL
 #define RT_TM(k)
@@ -481,7 +481,9 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
   // v_writelane / v_readlane instead of an LDS round trip per push and pop (measured +1.7 % on C2)
   int stk0 = 0, stk1 = 0;
   RT_TM_DECL
+  RT_TM_CNT(8)
   while (true) {
+    RT_TM_CNT(9)
     if (!have) {
       if (sp == 0) break;
       --sp;
@@ -507,6 +509,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
         const ChildRef far = left_first ? P.r : P.l;
         int m0_keep;                          // (v_writelane takes one SGPR operand besides the lane select in M0; M0 belongs to the compiler, so it is put back)
         asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2" : "+v"(stk0), "+v"(stk1), "=&s"(m0_keep) : "s"(far.i0), "s"(sp), "s"(far.i1)); sp++;
+        RT_TM_CNT(14)
         cur = left_first ? P.l : P.r; have = true;
       }
       else if (ml != 0ull) { cur = P.l; have = true; }
@@ -538,6 +541,10 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           const unsigned int lane = threadIdx.x & 63;
           const unsigned long long Wm = __ballot(want);
           const int n = __popcll(Wm);
+          RT_TM_CNT(10)
+#ifdef RT_TIMERS
+          tm_[13] += n;
+#endif
           const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(Wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Wm, 0u));
           if (want) lds->slot[rank] = lane;
           // q = L / n, j = L % n through a 16-bit reciprocal (exact for L < 64, n <= 64: checked exhaustively in tests)
@@ -556,6 +563,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           unsigned other = 0u;                       // records of kind 2 (spheres ...): exact test after the loop
           for (int b0i = 0; b0i < nrec; b0i += S) {
             if (ANY && __ballot(want && !found) == 0ull) break;      // every interested ray of the wave is occluded
+            RT_TM_CNT(11)
             const int rec = b0i + (int)q;
             const bool valid = lane_used && rec < nrec;
             const LeafRec &c = recs[valid ? rec : 0];
@@ -589,7 +597,11 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
             unsigned long long mine = want ? (ev & (stride_mask << rank)) : 0ull;
             const unsigned long long tbits = __double_as_longlong(tc);
             const int pack = prim | (untrusted ? (int)0x80000000 : 0);
+#ifdef RT_TIMERS
+            tm_[15] += __popcll(ev);
+#endif
             while (__ballot(mine != 0ull) != 0ull) {
+              RT_TM_CNT(12)
               const bool has = mine != 0ull;
               const int L = has ? (int)__builtin_ctzll(mine) : 0;
               mine &= mine - 1ull;

@@ -496,8 +496,8 @@ __device__ __forceinline__ void stamp(unsigned int wave, int which, int kernel =
 extern "C" int rt_hip_debug_read_timers(unsigned long long *out, int reset)
 {
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_timers), 16 * 8, 0, hipMemcpyDeviceToHost));
-  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_timers), z, sizeof z, 0, hipMemcpyHostToDevice)); }
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_timers), 32 * 8, 0, hipMemcpyDeviceToHost));
+  if (reset) { unsigned long long z[32] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_timers), z, sizeof z, 0, hipMemcpyHostToDevice)); }
   return 0;
 }
 #endif
@@ -1552,7 +1552,9 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
   unsigned int cap[rt_hip_scene::kMaxLevels] = {0};
   bool exact[rt_hip_scene::kMaxLevels] = {false};
   cap[0] = (unsigned int)n0; exact[0] = true;
-  constexpr uint64_t kLevelBudget = 6ull << 30;
+  // (2 GiB: a handle's grow-only workspace is the sum of its level arrays, and every shared handle in flight owns one -- a 1080p depth-8 glass
+  // frame ran blind up to 8 GiB per handle under the former 6 GiB bound; beyond the budget a level costs one 4-byte read-back)
+  constexpr uint64_t kLevelBudget = 2ull << 30;
   int depth = A.cam.depth < 1 ? 1 : A.cam.depth;
   if (depth > rt_hip_scene::kMaxLevels) return fail(RT_HIP_EUNSUPPORTED, "camera depth > 12: the sampler keys 12 bits of ray-tree path (rng_counter), deeper rays would share random streams");
   HIP_TRY(hipMemsetAsync(cnt->level_n, 0, sizeof cnt->level_n, st));
@@ -1849,6 +1851,18 @@ static int fill_args(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_par
   return RT_HIP_OK;
 }
 static bool tile_sharded(const RenderArgs &A) { return A.tile_stride > 1; }
+// A copy of a call's arguments over another range of whole pixel rows [v_first, v_last] (the anti-aliasing drivers' G-buffer with its halo rows):
+// everything fill_args derives from the rows -- the 8x8 tiling, the super-tile count that sizes level 0 and the launches, the output and
+// camera-ray counts -- is derived again, so that no user of the copy meets the original's figures.  Pixel shards only.
+static RenderArgs args_over_rows(const RenderArgs &A, uint32_t v_first, uint32_t v_last)
+{
+  RenderArgs G = A;
+  G.pixel_first = (uint64_t)v_first * A.cam.W; G.pixel_count = (uint64_t)(v_last - v_first + 1) * A.cam.W;
+  G.v_lo = v_first; G.tiles_y = (v_last - v_first + 8) / 8;
+  G.n_st = ((G.tiles_x + 15) / 16) * ((G.tiles_y + 7) / 8);
+  G.n_out = G.pixel_count; G.n_primary = G.pixel_count;
+  return G;
+}
 
 extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_params *P, double *d_rgb,
                                           int32_t *d_prim_id, void *stream)

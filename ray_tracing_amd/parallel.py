@@ -205,9 +205,10 @@ def render_whitted_tiles(rta, ctx, scene, camera, rank, world, background=(0, 0,
     if out is None:
         out = torch.zeros((per * 8192, 3), dtype=torch.uint8 if bgr8 else torch.float64, device="cuda")
     p = rta.Params(background=background, tile_offset=rank, tile_stride=world, frame_format=1 if bgr8 else 0)
-    s = stream if stream is not None else torch.cuda.current_stream()
+    s = _render_stream(stream)          # after the zero fill above (the current stream's), like the row and sample paths
     rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene if raw_scene is not None else scene.device(ctx), camera.raw, p, C.c_void_p(out.data_ptr()),
                                                 C.c_void_p(ids.data_ptr()) if ids is not None else None, C.c_void_p(s.cuda_stream)))
+    _join(s)                            # what the current stream does with `out` next (the all-gather) comes after the render
     return out
 
 
@@ -227,9 +228,10 @@ def tiles_to_frame(rta, camera, world, tiles, frame=None, stream=None, rank_pitc
     ch = tiles.shape[1] if tiles.dim() > 1 else 1
     if frame is None:
         frame = torch.empty((camera.height * camera.width, ch) if ch > 1 else (camera.height * camera.width,), dtype=tiles.dtype, device=tiles.device)
-    s = stream if stream is not None else torch.cuda.current_stream()
+    s = _render_stream(stream)          # after the all-gather that filled `tiles` on the current stream
     rta.check(rta.hip.rt_hip_tiles_to_frame_dev(camera.raw, world, C.c_void_p(tiles.data_ptr()), rank_pitch_bytes, tiles.element_size() * ch,
                                                 C.c_void_p(frame.data_ptr()), C.c_void_p(s.cuda_stream)))
+    _join(s)
     return frame
 
 

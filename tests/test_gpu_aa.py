@@ -105,6 +105,27 @@ def test_antialiasing_pixel_shards_reassemble(ctx):
     assert rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, bad, aa, full.ctypes.data, None) == -4
 
 
+def test_antialiasing_shards_of_whole_super_tile_rows(ctx):
+    """a shard of exactly 64 rows that starts at v_lo > 0: with its halo rows the G-buffer spans one more row of 64-row super-tiles than
+    the shard itself (the G pass must size its level 0 and its launch from its OWN rows)"""
+    import ray_tracing_amd as rta
+    g, _ = scenes.build_icosahedron(material="metal", light="point_area", extra_sphere=True)
+    cam = rta.Camera(**dict(scenes.C1_CAMERA, hor=3.6, ver=4.8, res=40, depth=2))
+    n, W = cam.width * cam.height, cam.width
+    assert cam.height == 192
+    aa = rta.AaParams(oversample_times=3)
+    full = np.zeros((n, 3)); fmask = np.zeros(n, dtype=np.uint8)
+    p = rta.Params(background=(200, 200, 200), seed=4)
+    rta.check(rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, p, aa, full.ctypes.data, fmask.ctypes.data))
+    assert fmask.sum() > 0
+    for a, b in ((64 * W, 128 * W), (128 * W, 192 * W), (0, 64 * W), (64 * W, 192 * W)):
+        q = rta.Params(background=(200, 200, 200), seed=4, pixel_first=a, pixel_count=b - a)
+        out = np.full((b - a, 3), -1.0); m = np.full(b - a, 7, dtype=np.uint8)
+        rta.check(rta.hip.rt_hip_render_antialiasing(g.device(ctx), cam.raw, q, aa, out.ctypes.data, m.ctypes.data))
+        assert (m == fmask[a:b]).all(), (a // W, b // W)
+        assert (out == full[a:b]).all(), (a // W, b // W)
+
+
 def test_resample_every_pixel(ctx):
     """a negative threshold is always exceeded: the driver becomes the fixed-spp jittered render (BASELINE config C4)"""
     import ray_tracing_amd as rta
