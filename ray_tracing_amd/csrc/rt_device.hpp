@@ -302,6 +302,23 @@ __device__ __forceinline__ bool slab_f(const RayState &r, float bound_f, const f
   return (tmin <= tmax) && (tmax >= 0.0f) && (tmin <= bound_f);
 }
 
+// The node step's form of slab_f: the answer for all 64 rays at once, as a lane mask.  A vote over a compound condition costs two vector
+// instructions beyond its compares (the condition is materialised per lane and compared again); a vote over ONE compare is that compare's own
+// result register.  So the three conditions of slab_f are folded into one: with bound_f >= 0 (every bound is a t + margin or kMiss),
+// tmin <= tmax && tmax >= 0 && tmin <= bound_f  <=>  max(tmin, 0) <= min(tmax, bound_f).
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool slab_hit_f(const RayState &r, float bound_f, const float *bmin, const float *bmax)
+{
+  float t1 = fmaf(bmin[0], r.fix, -r.fax), t2 = fmaf(bmax[0], r.fix, -r.fbx);
+  const float lx = __builtin_fminf(t1, t2), hx = __builtin_fmaxf(t1, t2);
+  t1 = fmaf(bmin[1], r.fiy, -r.fay); t2 = fmaf(bmax[1], r.fiy, -r.fby);
+  const float ly = __builtin_fminf(t1, t2), hy = __builtin_fmaxf(t1, t2);
+  t1 = fmaf(bmin[2], r.fiz, -r.faz); t2 = fmaf(bmax[2], r.fiz, -r.fbz);
+  const float lz = __builtin_fminf(t1, t2), hz = __builtin_fmaxf(t1, t2);
+  const float lo = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(lx, ly), lz), 0.0f), hi = __builtin_fminf(__builtin_fminf(__builtin_fminf(hx, hy), hz), bound_f);
+  return lo <= hi;
+}
+
 // can a Newton-solved object still matter to this ray?  Its accepted hits lie in [pmin, pmax] (rt_param.hpp: param_prune_box), in front of
 // the origin, and only those up to t_max can change the result.  Skipping the solve otherwise changes nothing but the time.
 __device__ __forceinline__ bool param_may_matter(const RayState &r, const double *pmin, const double *pmax, double t_max)
@@ -453,7 +470,6 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
   };
   int sp = 0;
   ChildRef cur = sc.root;
-  bool have = true;                                // `cur` holds the next node (the near child); else pop
   // Newton-solved objects met in leaves (fast walk only): queued, solved 64 pairs at a time, see PairQueue
   PairQueue *pq_ptr = nullptr;
   if constexpr (PARAM && DEFER) pq_ptr = &wave_pair_queue();
@@ -482,43 +498,46 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
   int stk0 = 0, stk1 = 0;
   RT_TM_DECL
   RT_TM_CNT(8)
-  while (true) {
-    RT_TM_CNT(9)
-    if (!have) {
-      if (sp == 0) break;
-      --sp;
-      cur.i0 = __builtin_amdgcn_readlane(stk0, sp); cur.i1 = __builtin_amdgcn_readlane(stk1, sp);
-    }
-    have = false;
-    const int i0 = cur.i0, i1 = cur.i1;
-    const bool live = active && !(ANY && found);
-    if (__ballot(live) == 0ull) break;            // every ray of the wave is finished
-    RT_TM(0)
-    if (i0 >= 0) {
-      // ---- inner node: fetch both child boxes at once, keep the children some lane wants ----
-      const DPairF P = load_pair(sc.pairs, i0);
-      const float bound_f = bound_up_f(r.bound);
-      const bool wl = slab_f(r, bound_f, P.lmin, P.lmax) & live;
-      const bool wr = slab_f(r, bound_f, P.rmin, P.rmax) & live;
-      if (STATS) { if (live) st.node_visits += 2; if ((threadIdx.x & 63) == 0) st.wave_nodes += 2; }
-      const unsigned long long ml = __ballot(wl), mr = __ballot(wr);
-      const unsigned long long pos = __ballot((wl | wr) & (((r.dsign >> i1) & 1u) != 0u));
-      const bool left_first = (2 * __popcll(pos) >= __popcll(ml | mr));
-      // continue with the near child; the far one waits on the stack
-      if (ml != 0ull && mr != 0ull) {
-        const ChildRef far = left_first ? P.r : P.l;
+  // Wave-level state of the node steps (lane masks in SGPRs, so that a step's votes are scalar algebra on its compares):
+  // the lanes that still walk, the lanes whose rays look along +x / +y / +z; and every lane's bound in FP32 (it only changes in leaves).
+  unsigned long long live_mask = ballot64(active && !(ANY && found));
+  const unsigned long long sgn_x = ballot64(r.d.x >= 0.0), sgn_y = ballot64(r.d.y >= 0.0), sgn_z = ballot64(r.d.z >= 0.0);
+  float bound_f = bound_up_f(r.bound);
+  if (live_mask != 0ull)                           // (0: every ray of the wave is finished)
+  for (;;) {
+    // ---- descent through inner nodes: fetch both child boxes at once, go on with the near child some lane wants, the far one waits on the
+    //      stack.  Nothing a leaf changes (bounds, survivors) is touched in here. ----
+    bool at_leaf = true;
+    while (cur.i0 >= 0) {
+      RT_TM_CNT(9)
+      RT_TM(0)
+      const DPairF P = load_pair(sc.pairs, cur.i0);
+      const unsigned long long ml = ballot64(slab_hit_f(r, bound_f, P.lmin, P.lmax)) & live_mask;
+      const unsigned long long mr = ballot64(slab_hit_f(r, bound_f, P.rmin, P.rmax)) & live_mask;
+      if (STATS) { if ((live_mask >> (threadIdx.x & 63)) & 1ull) st.node_visits += 2; if ((threadIdx.x & 63) == 0) st.wave_nodes += 2; }
+      const unsigned long long both = ml | mr;
+      RT_TM_CNT(5)
+      if (both == 0ull) { at_leaf = false; RT_TM(1) break; }
+      const unsigned long long sg = (cur.i1 == 0) ? sgn_x : ((cur.i1 == 1) ? sgn_y : sgn_z);     // i1: the split axis of this pair
+      const bool left_first = (2 * __popcll(both & sg) >= __popcll(both));                      // the majority's near side
+      const bool take_left = (mr == 0ull) | ((ml != 0ull) & left_first);
+      if ((ml != 0ull) & (mr != 0ull)) {
+        const ChildRef far = take_left ? P.r : P.l;
         int m0_keep;                          // (v_writelane takes one SGPR operand besides the lane select in M0; M0 belongs to the compiler, so it is put back)
         asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2" : "+v"(stk0), "+v"(stk1), "=&s"(m0_keep) : "s"(far.i0), "s"(sp), "s"(far.i1)); sp++;
         RT_TM_CNT(14)
-        cur = left_first ? P.l : P.r; have = true;
       }
-      else if (ml != 0ull) { cur = P.l; have = true; }
-      else if (mr != 0ull) { cur = P.r; have = true; }
-      RT_TM(1) RT_TM_CNT(5)
-    } else {
+      cur = take_left ? P.l : P.r;
+      RT_TM(1)
+    }
+    if (at_leaf) {
+      RT_TM_CNT(9)
+      RT_TM(0)
+      const int i0 = cur.i0, i1 = cur.i1;
       // ---- leaf: stage header + records in LDS chunk by chunk ----
       const int cnt = -1 - i0;
       const unsigned char *base = sc.leaf_stream + (size_t)(unsigned)i1 * 64;
+      const bool live = active && !(ANY && found);
       bool want = false;
       for (int c0 = 0; c0 < cnt; c0 += RT_CHUNK_RECS) {
         const int nrec = (cnt - c0 < RT_CHUNK_RECS) ? (cnt - c0) : RT_CHUNK_RECS;
@@ -526,7 +545,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
         RT_TM(2) RT_TM_CNT(6)
         if (c0 == 0) {
           const LeafHeader *H = (const LeafHeader *)lds->leaf;
-          want = live && slab_f(r, bound_up_f(r.bound), H->bmin, H->bmax);
+          want = live && slab_hit_f(r, bound_f, H->bmin, H->bmax);
           if (STATS) { if (live) st.node_visits++; if ((threadIdx.x & 63) == 0) st.wave_nodes++; }
           if (__ballot(want) == 0ull) break;
         }
@@ -731,7 +750,13 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
         tm_[7] += nrec;
 #endif
       }
+      // what a leaf can change for the node steps: the bounds, and (occlusion) who still walks
+      bound_f = bound_up_f(r.bound);
+      if (ANY) live_mask = ballot64(active && !found);
     }
+    if (sp == 0 || (ANY && live_mask == 0ull)) break;
+    --sp;
+    cur.i0 = __builtin_amdgcn_readlane(stk0, sp); cur.i1 = __builtin_amdgcn_readlane(stk1, sp);
   }
   solve_pairs(1);
   RT_TM_FLUSH
