@@ -558,7 +558,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           // origin/direction/bound it gathers from LDS.  Survivors (rare) are handed back to the owning lane,
           // in record order per ray, which then does exactly what the broadcast loop did. ----
           const unsigned int lane = threadIdx.x & 63;
-          const unsigned long long Wm = __ballot(want);
+          const unsigned long long Wm = ballot64(want);
           const int n = __popcll(Wm);
           RT_TM_CNT(10)
 #ifdef RT_TIMERS
@@ -570,23 +570,30 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           const unsigned int magic = (unsigned int)uni((int)((unsigned int)(65536.0f * __builtin_amdgcn_rcpf((float)n)) + 2u));
           const unsigned int q = (lane * magic) >> 16, j = lane - q * (unsigned)n;
           const int S = (int)((64u * magic) >> 16);          // records in flight per step = 64 / n
-          const bool lane_used = (int)q < S;
           // bits 0, n, 2n, ... (S of them): the lanes that hold the records of the ray of rank 0; shifted by k for the ray of rank k
           unsigned long long stride_mask = 1ull;
           for (int span = n; span < S * n; span <<= 1) stride_mask |= stride_mask << span;
           if (S * n < 64) stride_mask &= (1ull << (S * n)) - 1ull;
+          const unsigned long long my_events = want ? (stride_mask << rank) : 0ull;      // where this lane's ray has its records culled
+          const unsigned long long used_mask = (S * n < 64) ? ((1ull << (S * n)) - 1ull) : ~0ull;   // lanes with q < S
           const unsigned int src = lds->slot[j];
           const RayLds &gr = lds->rays[src];
-          const double gox = gr.o[0], goy = gr.o[1], goz = gr.o[2], gdx = gr.d[0], gdy = gr.d[1], gdz = gr.d[2], gbound = gr.bound;
+          const double gox = gr.o[0], goy = gr.o[1], goz = gr.o[2], gdx = gr.d[0], gdy = gr.d[1], gdz = gr.d[2], ghi = gr.bound + r.tmargin;
           if (STATS && (threadIdx.x & 63) == 0) st.wave_prims += nrec;
-          unsigned other = 0u;                       // records of kind 2 (spheres ...): exact test after the loop
-          for (int b0i = 0; b0i < nrec; b0i += S) {
-            if (ANY && __ballot(want && !found) == 0ull) break;      // every interested ray of the wave is occluded
+          // records of kind 2 (spheres ...): exact test after the loop.  Found once per chunk (lane i looks at record i), not once per step.
+          unsigned other = (unsigned)(ballot64(recs[lane < 31u ? lane : 30u].kind == 2) & ((1ull << nrec) - 1ull));
+          // the interested rays that are still open (occlusion: not yet occluded), so that the step loop can end without a vote
+          unsigned long long open_mask = Wm;
+          if (ANY) open_mask &= ~ballot64(found);
+          const unsigned int end_off = (unsigned)nrec * (unsigned)sizeof(LeafRec);
+          unsigned int off = q * (unsigned)sizeof(LeafRec);   // this lane's record of the step, as a byte offset
+          for (int b0i = 0; b0i < nrec; b0i += S, off += (unsigned)S * (unsigned)sizeof(LeafRec)) {
+            if (ANY && open_mask == 0ull) break;                      // every interested ray of the wave is occluded
             RT_TM_CNT(11)
-            const int rec = b0i + (int)q;
-            const bool valid = lane_used && rec < nrec;
-            const LeafRec &c = recs[valid ? rec : 0];
-            if (STATS && valid) st.prim_tests++;
+            const unsigned long long valid_mask = used_mask & ballot64(off < end_off);
+            const unsigned int coff = off < end_off ? off : end_off - (unsigned)sizeof(LeafRec);       // (a lane without a record culls the chunk's last one; its vote is masked)
+            const LeafRec &c = *(const LeafRec *)((const unsigned char *)recs + coff);
+            if (STATS && ((valid_mask >> lane) & 1ull)) st.prim_tests++;
             const double n0 = c.n[0], n1 = c.n[1], n2 = c.n[2], dpl = c.dpl;
             const double B0 = c.B[0], B1 = c.B[1], B2 = c.B[2], b0 = c.b0;
             const double G0 = c.G[0], G1 = c.G[1], G2 = c.G[2], g0 = c.g0;
@@ -602,24 +609,25 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
             const double be = fma(pz, B2, fma(py, B1, fma(px, B0, b0)));
             const double ga = fma(pz, G2, fma(py, G1, fma(px, G0, g0)));
             const double m = fma(r.mscale, bsum, 1e-6);
-            const bool untrusted = !(fabs(g) >= r.gmin) | (kind == 1);      // also catches NaN
-            const bool inside = (tc > kEps - r.tlow * fabs(rg)) & (tc < gbound + r.tmargin) & (be > -m) & (ga > -m) & (be + ga < 1.0 + m);
-            // kind-2 records: remember their index (one lane per record speaks)
-            unsigned long long om = __ballot(valid & (kind == 2) & (j == 0u));
-            while (om) { const int L = __builtin_ctzll(om); om &= om - 1ull; other |= 1u << (b0i + (int)(((unsigned)L * magic) >> 16)); }
+            // a record whose cull data are unusable (kind 1) carries a zero normal: g = 0, never trusted.  Also catches NaN.
+            const bool untrusted = !(fabs(g) >= r.gmin);
+            // every vote below is over ONE compare (its result register is the vote); the conditions meet as scalar algebra
+            const unsigned long long inside_mask = ballot64(tc > kEps - r.tlow * fabs(rg)) & ballot64(tc < ghi) & ballot64(be > -m) & ballot64(ga > -m) &
+                                                   ballot64(be + ga < 1.0 + m);
             // ---- events back to the owners, ascending lane = ascending record per ray ----
-            const unsigned long long ev = __ballot(valid & (kind != 2) & (untrusted | inside));
+            unsigned long long ev = valid_mask & ballot64(kind != 2) & (ballot64(untrusted) | inside_mask);
+            asm("" : "+s"(ev));        // (ev is finished in SGPRs before the per-lane AND below: left alone, the compiler ANDs every factor into the lane pattern separately)
             // Every owner takes ITS events together with the other owners: the events of the ray of rank k sit in lanes k, k + n, k + 2n, ...
             // (ascending lane = ascending record), so an owner masks ev with that stride pattern and pulls the (t', prim, untrusted) of its
             // lowest event from the lane that holds it with ds_bpermute; one round per event of the busiest ray of the step (mostly one),
             // where the former loop took one round per event of the step (~5).
-            unsigned long long mine = want ? (ev & (stride_mask << rank)) : 0ull;
+            unsigned long long mine = ev & my_events;
             const unsigned long long tbits = __double_as_longlong(tc);
             const int pack = prim | (untrusted ? (int)0x80000000 : 0);
 #ifdef RT_TIMERS
             tm_[15] += __popcll(ev);
 #endif
-            while (__ballot(mine != 0ull) != 0ull) {
+            while (ballot64(mine != 0ull) != 0ull) {
               RT_TM_CNT(12)
               const bool has = mine != 0ull;
               const int L = has ? (int)__builtin_ctzll(mine) : 0;
@@ -630,25 +638,26 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
               const double etc = __longlong_as_double(((unsigned long long)ehi << 32) | (unsigned long long)elo);
               const int eprim = epack & 0x7FFFFFFF;
               const bool eun = epack < 0;
-              if (has && !(ANY && found)) {
-                if (eun) D.redo = true;
-                else if (etc < r.bound + r.tmargin) {          // the owner's current bound (the gathered one may be older)
-                  if (ANY) {
-                    // may this survivor occlude?  f(t) = Dot(o - X, ref - X), X = o + d t (Scene.h:449)
-                    bool maybe = true;
-                    if (has_ref) {
-                      V3 X = mk(fma(r.d.x, etc, r.o.x), fma(r.d.y, etc, r.o.y), fma(r.d.z, etc, r.o.z));
-                      maybe = dot(r.o - X, ref - X) < -kEps + fmargin;
-                    }
-                    if (maybe) { found = true; D.c1_id = eprim; D.c1_t = etc; }
-                  } else if (eprim != D.c1_id && eprim != D.c2_id) {
-                    if (etc < D.c1_t) { D.c3_t = fmin(D.c3_t, D.c2_t); D.c2_t = D.c1_t; D.c2_id = D.c1_id; D.c1_t = etc; D.c1_id = eprim; }
-                    else if (etc < D.c2_t) { D.c3_t = fmin(D.c3_t, D.c2_t); D.c2_t = etc; D.c2_id = eprim; }
-                    else D.c3_t = fmin(D.c3_t, etc);
-                    r.bound = fmin(r.bound, D.c1_t + 2.0 * r.tmargin);
-                    lds->rays[lane].bound = r.bound;
-                  }
+              const bool open = has && !(ANY && found);
+              if (open && eun) D.redo = true;
+              const bool cand = open && !eun && etc < r.bound + r.tmargin;      // the owner's current bound (the gathered one may be older)
+              if (ANY) {
+                // may this survivor occlude?  f(t) = Dot(o - X, ref - X), X = o + d t (Scene.h:449)
+                bool maybe = cand;
+                if (has_ref) {
+                  V3 X = mk(fma(r.d.x, etc, r.o.x), fma(r.d.y, etc, r.o.y), fma(r.d.z, etc, r.o.z));
+                  maybe = cand && dot(r.o - X, ref - X) < -kEps + fmargin;
                 }
+                if (maybe) { found = true; D.c1_id = eprim; D.c1_t = etc; }
+                open_mask &= ~ballot64(maybe);
+              } else if (cand && eprim != D.c1_id && eprim != D.c2_id) {
+                // the two nearest survivors stay sorted, the nearest discarded one is remembered (selects, no nested branches)
+                const bool lt1 = etc < D.c1_t, lt2 = etc < D.c2_t;
+                D.c3_t = fmin(D.c3_t, lt2 ? D.c2_t : etc);
+                D.c2_t = lt1 ? D.c1_t : (lt2 ? etc : D.c2_t); D.c2_id = lt1 ? D.c1_id : (lt2 ? eprim : D.c2_id);
+                D.c1_t = lt1 ? etc : D.c1_t; D.c1_id = lt1 ? eprim : D.c1_id;
+                r.bound = fmin(r.bound, D.c1_t + 2.0 * r.tmargin);
+                lds->rays[lane].bound = r.bound;
               }
             }
           }
@@ -728,7 +737,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
               if (STATS) st.exact_tests++;
               const TriExact &T = sc.tri_exact[uni(c.tri_idx)];
               double t = tri_exact_t(mk(T.v0[0], T.v0[1], T.v0[2]), mk(T.v1[0], T.v1[1], T.v1[2]), mk(T.v2[0], T.v2[1], T.v2[2]),
-                                     mk(n0, n1, n2), r.o, r.d);
+                                     mk(T.nrm[0], T.nrm[1], T.nrm[2]), r.o, r.d);
               confirmed(t, prim, true);
             }
           }

@@ -212,8 +212,7 @@ struct Builder {
     if (d->obj_type[prim] != RT_HIP_TRIANGLE) { c.kind = 2; return c; }
     c.tri_idx = (int32_t)d->obj_index[prim];
     const TriExact &T = tri_exact[d->obj_index[prim]];
-    std::memcpy(c.n, T.nrm, 24);     // m_norm, used by the confirm step in every case
-    c.kind = 1;                      // until the cull data prove usable
+    c.kind = 1;                      // until the cull data prove usable: the normal stays zero, so that d.n = 0 marks the record untrusted by itself
     V3 v0 = mk(T.v0[0], T.v0[1], T.v0[2]), v1 = mk(T.v1[0], T.v1[1], T.v1[2]), v2 = mk(T.v2[0], T.v2[1], T.v2[2]);
     V3 n = mk(T.nrm[0], T.nrm[1], T.nrm[2]);
     V3 e1 = v1 - v0, e2 = v2 - v0;
@@ -231,6 +230,7 @@ struct Builder {
     c.dpl = dpl;
     c.B[0] = B.x; c.B[1] = B.y; c.B[2] = B.z; c.b0 = b0;
     c.G[0] = G.x; c.G[1] = G.y; c.G[2] = G.z; c.g0 = g0;
+    std::memcpy(c.n, T.nrm, 24);     // m_norm
     c.bsum = bsum; c.kind = 0;
     return c;
   }
