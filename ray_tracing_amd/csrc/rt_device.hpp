@@ -435,6 +435,29 @@ __device__ __forceinline__ int pairs_push(PairQueue &Q, int n, bool want, int id
   return n + __popcll(m);
 }
 
+// How n interested rays x the records of a chunk are dealt over the 64 lanes (redistributed cull, see walk): lane L culls record L / n of the step
+// for the ray of rank L % n.  Per n: the 16-bit reciprocal that divides a lane number by n exactly (floor(65536 / n) + 2; checked for
+// every L < 64, n <= 64 in the tests), S = 64 / n records per step, the lanes in use (S * n of them), and the lanes that hold the records of the
+// ray of rank 0 (bits 0, n, 2n, ...).  One 32-byte scalar load per chunk instead of a reciprocal in the vector unit and two scalar loops.
+struct alignas(32) DealRow { unsigned int magic, S; unsigned long long stride_mask, used_mask, pad; };
+struct DealTable { DealRow row[65]; };
+constexpr DealTable make_deal_table()
+{
+  DealTable t{};
+  for (unsigned int n = 1; n <= 64; n++) {
+    t.row[n].magic = 65536u / n + 2u;
+    const unsigned int S = 64u / n;
+    t.row[n].S = S;
+    unsigned long long m = 0;
+    for (unsigned int k = 0; k < S; k++) m |= 1ull << (k * n);
+    t.row[n].stride_mask = m;
+    t.row[n].used_mask = (S * n < 64u) ? ((1ull << (S * n)) - 1ull) : ~0ull;
+  }
+  t.row[0] = t.row[1]; t.row[0].used_mask = 0;
+  return t;
+}
+__constant__ const DealTable kDeal = make_deal_table();
+
 // Deferred-confirmation state of one ray.  During the fast walk only the cull runs; the two nearest
 // cull survivors (by t') are remembered and confirmed once, after the walk, by all lanes together.
 // A lane whose survivors are not conclusive (see finish_closest / finish_any) is re-walked with the
@@ -515,9 +538,57 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
       const unsigned long long ml = ballot64(slab_hit_f(r, bound_f, P.lmin, P.lmax)) & live_mask;
       const unsigned long long mr = ballot64(slab_hit_f(r, bound_f, P.rmin, P.rmax)) & live_mask;
       if (STATS) { if ((live_mask >> (threadIdx.x & 63)) & 1ull) st.node_visits += 2; if ((threadIdx.x & 63) == 0) st.wave_nodes += 2; }
-      const unsigned long long both = ml | mr;
       RT_TM_CNT(5)
-      if (both == 0ull) { at_leaf = false; RT_TM(1) break; }
+#ifdef RT_ASM_STEP
+      // (experiment, measured -0.8 % on C2: the same decisions written out for the scalar unit -- 24 scalar instructions and 2 branches per step
+      // instead of the compiler's 46 and 6, but a block the scheduler cannot move the next step's work across)
+      // Which child next, which one waits: wave-uniform decisions on the two votes, written out for the scalar unit (left to the compiler,
+      // uniform predicates that are and-ed / or-ed live as 64-bit lane masks and every use costs a mask-to-condition round trip: 46 scalar
+      // instructions and 6 branches per step instead of 24 and 2).
+      //   n_both = rays that want a child (0: dead end); near = left iff (mr == 0) or (ml != 0 and the majority of the interested rays looks
+      //   along the split axis from the left side); the far child is written to stack slot sp in any case, sp moves only if both are wanted.
+      const unsigned long long sg = (cur.i1 == 0) ? sgn_x : ((cur.i1 == 1) ? sgn_y : sgn_z);     // i1: the split axis of this pair
+      int n_both, near0, near1, far0, far1, tl_, push_, m0_keep;
+      unsigned long long t_;
+      asm volatile("s_or_b64 %[t], %[ml], %[mr]\n\t"
+                   "s_bcnt1_i32_b64 %[nb], %[t]\n\t"
+                   "s_and_b64 %[t], %[t], %[sg]\n\t"
+                   "s_bcnt1_i32_b64 %[tl], %[t]\n\t"
+                   "s_lshl_b32 %[tl], %[tl], 1\n\t"
+                   "s_cmp_ge_u32 %[tl], %[nb]\n\t"
+                   "s_cselect_b32 %[tl], 1, 0\n\t"
+                   "s_cmp_lg_u64 %[ml], 0\n\t"
+                   "s_cselect_b32 %[tl], %[tl], 0\n\t"
+                   "s_cselect_b32 %[pu], 1, 0\n\t"
+                   "s_cmp_lg_u64 %[mr], 0\n\t"
+                   "s_cselect_b32 %[tl], %[tl], 1\n\t"
+                   "s_cselect_b32 %[pu], %[pu], 0\n\t"
+                   "s_cmp_lg_u32 %[tl], 0\n\t"
+                   "s_cselect_b32 %[n0], %[l0], %[r0]\n\t"
+                   "s_cselect_b32 %[n1], %[l1], %[r1]\n\t"
+                   "s_cselect_b32 %[f0], %[r0], %[l0]\n\t"
+                   "s_cselect_b32 %[f1], %[r1], %[l1]\n\t"
+                   "s_mov_b32 %[mk], m0\n\t"         // (M0 belongs to the compiler: put back)
+                   "s_mov_b32 m0, %[sp]\n\t"
+                   "s_nop 0\n\t"
+                   "v_writelane_b32 %[k0], %[f0], m0\n\t"
+                   "v_writelane_b32 %[k1], %[f1], m0\n\t"
+                   "s_mov_b32 m0, %[mk]"
+                   : [t] "=&s"(t_), [nb] "=&s"(n_both), [tl] "=&s"(tl_), [pu] "=&s"(push_), [n0] "=&s"(near0), [n1] "=&s"(near1), [f0] "=&s"(far0), [f1] "=&s"(far1),
+                     [mk] "=&s"(m0_keep), [k0] "+v"(stk0), [k1] "+v"(stk1)
+                   : [ml] "s"(ml), [mr] "s"(mr), [sg] "s"(sg), [l0] "s"(P.l.i0), [l1] "s"(P.l.i1), [r0] "s"(P.r.i0), [r1] "s"(P.r.i1), [sp] "s"(sp)
+                   : "scc");
+      // (what an asm statement returns counts as divergent: uni() says otherwise, and costs nothing on a value that is in an SGPR already)
+      if (uni(n_both) == 0) { at_leaf = false; RT_TM(1) break; }    // no ray wants either child
+      sp += uni(push_);
+#ifdef RT_TIMERS
+      tm_[14] += push_;
+#endif
+      cur.i0 = uni(near0); cur.i1 = uni(near1);
+      RT_TM(1)
+#else
+      const unsigned long long both = ml | mr;
+      if (both == 0ull) { at_leaf = false; RT_TM(1) break; }        // no ray wants either child
       const unsigned long long sg = (cur.i1 == 0) ? sgn_x : ((cur.i1 == 1) ? sgn_y : sgn_z);     // i1: the split axis of this pair
       const bool left_first = (2 * __popcll(both & sg) >= __popcll(both));                      // the majority's near side
       const bool take_left = (mr == 0ull) | ((ml != 0ull) & left_first);
@@ -529,6 +600,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
       }
       cur = take_left ? P.l : P.r;
       RT_TM(1)
+#endif
     }
     if (at_leaf) {
       RT_TM_CNT(9)
@@ -539,15 +611,17 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
       const unsigned char *base = sc.leaf_stream + (size_t)(unsigned)i1 * 64;
       const bool live = active && !(ANY && found);
       bool want = false;
+      unsigned long long Wm = 0ull;                 // the rays that want this leaf, as a mask
       for (int c0 = 0; c0 < cnt; c0 += RT_CHUNK_RECS) {
         const int nrec = (cnt - c0 < RT_CHUNK_RECS) ? (cnt - c0) : RT_CHUNK_RECS;
         stage_chunk(base + (size_t)c0 * sizeof(LeafRec), lds->leaf, 64 + nrec * (int)sizeof(LeafRec));
         RT_TM(2) RT_TM_CNT(6)
         if (c0 == 0) {
           const LeafHeader *H = (const LeafHeader *)lds->leaf;
-          want = live && slab_hit_f(r, bound_f, H->bmin, H->bmax);
+          const bool in_box = slab_hit_f(r, bound_f, H->bmin, H->bmax);
+          want = live && in_box; Wm = ballot64(in_box) & live_mask;
           if (STATS) { if (live) st.node_visits++; if ((threadIdx.x & 63) == 0) st.wave_nodes++; }
-          if (__ballot(want) == 0ull) break;
+          if (Wm == 0ull) break;
         }
         RT_TM(3)
         const LeafRec *recs = (const LeafRec *)(lds->leaf + 64);
@@ -558,7 +632,6 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           // origin/direction/bound it gathers from LDS.  Survivors (rare) are handed back to the owning lane,
           // in record order per ray, which then does exactly what the broadcast loop did. ----
           const unsigned int lane = threadIdx.x & 63;
-          const unsigned long long Wm = ballot64(want);
           const int n = __popcll(Wm);
           RT_TM_CNT(10)
 #ifdef RT_TIMERS
@@ -566,16 +639,18 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
 #endif
           const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(Wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Wm, 0u));
           if (want) lds->slot[rank] = lane;
-          // q = L / n, j = L % n through a 16-bit reciprocal (exact for L < 64, n <= 64: checked exhaustively in tests)
-          const unsigned int magic = (unsigned int)uni((int)((unsigned int)(65536.0f * __builtin_amdgcn_rcpf((float)n)) + 2u));
+          // the deal of this chunk (kDeal): q = L / n, j = L % n, S = 64 / n records in flight per step
+#if defined(__HIP_DEVICE_COMPILE__)
+          const DealRow deal = *(const __attribute__((address_space(4))) DealRow *)(unsigned long long)(&kDeal.row[n]);   // (one s_load_dwordx8, like load_pair)
+#else
+          const DealRow deal = kDeal.row[n];
+#endif
+          const unsigned long long used_mask = deal.used_mask;                           // lanes with q < S
+          const unsigned int magic = deal.magic;
           const unsigned int q = (lane * magic) >> 16, j = lane - q * (unsigned)n;
-          const int S = (int)((64u * magic) >> 16);          // records in flight per step = 64 / n
-          // bits 0, n, 2n, ... (S of them): the lanes that hold the records of the ray of rank 0; shifted by k for the ray of rank k
-          unsigned long long stride_mask = 1ull;
-          for (int span = n; span < S * n; span <<= 1) stride_mask |= stride_mask << span;
-          if (S * n < 64) stride_mask &= (1ull << (S * n)) - 1ull;
-          const unsigned long long my_events = want ? (stride_mask << rank) : 0ull;      // where this lane's ray has its records culled
-          const unsigned long long used_mask = (S * n < 64) ? ((1ull << (S * n)) - 1ull) : ~0ull;   // lanes with q < S
+          const int S = (int)deal.S;
+          // deal.stride_mask: the lanes that hold the records of the ray of rank 0; shifted by k for the ray of rank k
+          const unsigned long long my_events = want ? (deal.stride_mask << rank) : 0ull;  // where this lane's ray has its records culled
           const unsigned int src = lds->slot[j];
           const RayLds &gr = lds->rays[src];
           const double gox = gr.o[0], goy = gr.o[1], goz = gr.o[2], gdx = gr.d[0], gdy = gr.d[1], gdz = gr.d[2], ghi = gr.bound + r.tmargin;
