@@ -36,9 +36,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_VALU_PEAK_TF = 78.6     # MI355X vector FP64 (FMA = 2 flop): 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz
 N_SIMD = 1024                # 256 CUs x 4 SIMDs
-CLOCK_GHZ = 2.4              # peak engine clock; a wave64 VALU instruction occupies its SIMD for 4 cycles
-VALU_ISSUE_PEAK_G = N_SIMD * CLOCK_GHZ / 4.0      # 614.4 G wave-instructions/s: the roof the walk kernels are bound by
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+N_CU = 256
+CLOCK_GHZ = 2.4              # peak engine clock
+# MI355X_MICROARCH.md (lines 54, 485): the SIMDs are 32 lanes wide, so a wave64 FP32 / integer / move instruction issues over 2 cycles (with a second wave
+# resident), an FP64 one over 4 (78.6 TF FP64 vector = half the 157.3 TF FP32 vector peak).  The VALU roof of a kernel therefore depends on its
+# instruction mix: peak = 1024 SIMDs x 2.4 GHz / (4 f64_share + 2 (1 - f64_share)) wave-instructions/s, f64_share from the per-type SQ counters.
+VALU_ISSUE_PEAK_ALL_F64_G = N_SIMD * CLOCK_GHZ / 4.0      # 614.4 G wave-instructions/s if every instruction were FP64 (round 2's constant)
+VALU_ISSUE_PEAK_ALL_F32_G = N_SIMD * CLOCK_GHZ / 2.0      # 1228.8 if none were
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json")]
+
+
+def valu_peak_g(f64_share):
+    """mix-weighted VALU issue roof in G wave-instructions/s"""
+    return N_SIMD * CLOCK_GHZ / (4.0 * f64_share + 2.0 * (1.0 - f64_share))
 
 
 def parse_args():
@@ -58,6 +68,7 @@ def parse_args():
     ap.add_argument("--emulate-world", type=int, default=0, help="one GPU renders rank 0's share of an N-rank run, no collective (tuning aid; not a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (reference tree, f64 frame, other configs)")
+    ap.add_argument("--others", choices=["full", "short"], default="full", help="C3 / C4 / C5 inside the default line: at BASELINE's full sizes (1024 spp, 256 spp, 10 M photons; ~10 s of GPU time together) or cut down and extrapolated")
     ap.add_argument("--spp", type=int, default=0, help="C3 / C4: samples per pixel timed per step (0 = a short default; the full config is 1024 / 256)")
     ap.add_argument("--photons", type=int, default=0, help="C5: photons per light sample and pass (0 = a short default; the full config is 400000)")
     return ap.parse_args()
@@ -143,12 +154,65 @@ def last_rays(rta, raw):
     return a.value, b.value
 
 
+def traffic_file():
+    for f in TRAFFIC_FILES:
+        if os.path.exists(f):
+            return f
+    return TRAFFIC_FILES[0]
+
+
 def read_traffic(kernel):
-    """per-launch PMC figures of `kernel` from the committed rocprofv3 passes (profiles/r02_traffic.json), or {}"""
+    """per-launch PMC figures of `kernel` from the committed rocprofv3 passes (profiles/r03_traffic.json), or {}"""
     try:
-        return json.load(open(TRAFFIC_FILE)).get(kernel, {})
+        return json.load(open(traffic_file())).get(kernel, {})
     except Exception:
         return {}
+
+
+def counters_stale():
+    """do the committed counters belong to the library being timed?  True / False, None when the file carries no stamp.
+    (tools/collect_profiles.sh stamps the sha256 of the librt_hip.so it profiled; the same file travels to the GPU box.)"""
+    import hashlib
+    try:
+        want = json.load(open(traffic_file())).get("_build", {}).get("librt_hip_so_sha256")
+    except Exception:
+        want = None
+    if not want:
+        return None
+    lib_dir = os.path.join(ROOT, "ray_tracing_amd", "lib")
+    path = os.environ.get("RT_HIP_LIB")
+    path = os.path.normpath(os.path.join(lib_dir, path)) if path else os.path.join(lib_dir, "librt_hip.so")
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest() != want
+    except OSError:
+        return None
+
+
+def issue_roofline(pmc, kernel_ms):
+    """the VALU-issue roofline of one kernel from its per-launch counters and a live kernel time: achieved wave-instructions/s against the
+    mix-weighted peak, and the scalar unit's share beside it (one scalar issue per CU and cycle)"""
+    vi = pmc.get("SQ_INSTS_VALU")
+    if not vi or not kernel_ms:
+        return {}
+    ach = vi / (kernel_ms * 1e-3) / 1e9
+    share = pmc.get("valu_f64_share")
+    out = {"achieved": round(ach, 1), "unit": "G wave-instructions/s"}
+    if share is not None:
+        peak = valu_peak_g(share)
+        out.update({"peak": round(peak, 1), "frac": round(ach / peak, 4), "valu_f64_share": round(share, 4), "valu_other_share": round(1.0 - share, 4),
+                    "peak_definition": "1024 SIMDs x 2.4 GHz / (4 cycles x f64_share + 2 cycles x the rest) per wave64 instruction (MI355X_MICROARCH.md)"})
+    else:
+        out.update({"peak": VALU_ISSUE_PEAK_ALL_F64_G, "frac": round(ach / VALU_ISSUE_PEAK_ALL_F64_G, 4),
+                    "peak_definition": "no per-type counters for this kernel: every instruction charged 4 cycles (an upper bound of the fraction)"})
+    out["frac_if_all_4_cycles"] = round(ach / VALU_ISSUE_PEAK_ALL_F64_G, 4)
+    out["frac_if_all_2_cycles"] = round(ach / VALU_ISSUE_PEAK_ALL_F32_G, 4)
+    sq = pmc.get("sq", {})
+    salu = sq.get("SQ_INSTS_SALU")
+    if salu:
+        cycles = kernel_ms * 1e-3 * CLOCK_GHZ * 1e9
+        out["salu_issue"] = {"frac": round(salu / N_CU / cycles, 4), "wave_insts_per_launch": salu,
+                             "definition": "SQ_INSTS_SALU / 256 CUs / kernel cycles at 2.4 GHz: the scalar unit is shared by a CU's four SIMDs"}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -238,17 +302,21 @@ def bench_c2(args, D, torch, rta, W):
                 rta.check(rta.hip.rt_hip_render_whitted_dev(handles[k], cams[fr % 32].raw, params_full, C.c_void_p(frames[0][f % frames[0].shape[0]].data_ptr()), None,
                                                             C.c_void_p(streams[k].cuda_stream)))
 
-    # ---- rays per frame (the census of the kernels themselves) ----
-    if tiles_mode:
-        rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cam0.raw, params_tile, C.c_void_p(send[0].data_ptr()), None, None))
-    else:
-        rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cam0.raw, params_full, C.c_void_p(frames[0][0].data_ptr()), None, None))
-    torch.cuda.synchronize()
-    my_rays, my_shadow = last_rays(rta, raw_scene)
-    if tiles_mode:
-        rays_per_frame = D.reduce(my_rays, "sum") if not emulate else float(my_rays) * tw
-    else:
-        rays_per_frame = float(my_rays)
+    # ---- rays per frame: the census of the kernels themselves, taken for every one of the 32 cameras the timed frames cycle through ----
+    cam_rays = []
+    for cm in cams:
+        if tiles_mode:
+            rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cm.raw, params_tile, C.c_void_p(send[0].data_ptr()), None, None))
+        else:
+            rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cm.raw, params_full, C.c_void_p(frames[0][0].data_ptr()), None, None))
+        torch.cuda.synchronize()
+        cam_rays.append(float(last_rays(rta, raw_scene)[0]))
+    my_rays = cam_rays[0]
+    if tiles_mode and not emulate:
+        cam_rays = [D.reduce(x, "sum") for x in cam_rays]
+    elif tiles_mode:
+        cam_rays = [x * tw for x in cam_rays]
+    rays_per_frame = sum(cam_rays) / len(cam_rays)           # mean over the cameras (reported); the rate below sums the frames actually timed
 
     for w in range(args.warmup):
         one_step(w)
@@ -264,7 +332,12 @@ def bench_c2(args, D, torch, rta, W):
     if rank != 0:
         return None
     ms_per_step = elapsed * 1e3 / args.steps
-    value = rays_per_frame * frames_total / elapsed / 1e6
+    # the rays of the frames that were timed: frame f of a rank uses camera f % 32 (replicas: (f x world + rank) % 32, every camera alike in the mean)
+    if world > 1 and not tiles_mode:
+        rays_timed = rays_per_frame * frames_total
+    else:
+        rays_timed = sum(cam_rays[f % 32] for f in range(F * args.steps))
+    value = rays_timed / elapsed / 1e6
     scaling = "strong" if (tiles_mode or world == 1) else "weak"
 
     out = {"metric": "Mrays/sec (primary+secondary)", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
@@ -272,7 +345,7 @@ def bench_c2(args, D, torch, rta, W):
            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "C2: synthetic %d-triangle heightfield + ground plane, primary+shadow ray casting %dx%d; a step = %d frames (camera swinging <= 1.8 deg around "
                                   "the C2 view), each to the Vec3b picture of Camera.h:69" % (n_tris, Wd, Ht, F),
-                      "triangles": n_tris, "resolution": [Wd, Ht], "frames_per_step": F, "rays_per_frame": int(rays_per_frame),
+                      "triangles": n_tris, "resolution": [Wd, Ht], "frames_per_step": F, "rays_per_frame": int(rays_per_frame), "rays_per_frame_definition": "mean of the kernels' own census over the 32 cameras of the orbit; value = the timed frames' rays, camera by camera, / time",
                       "ms_per_frame": round(ms_per_step / F, 4), "frames_in_flight": S,
                       "parallelism": ("one frame split over %d ranks by interleaved 128x64 super-tiles, %d-frame all-gather: %s" % (tw, G, comm_kind)) if tiles_mode
                                      else ("replicas x%d (no collective)" % world if world > 1 else "1 GPU"),
@@ -298,10 +371,14 @@ def bench_c2(args, D, torch, rta, W):
             dom = max(kms, key=lambda k: kms[k])
             pmc = read_traffic(dom)
             share = float(my_rays) / max(1.0, rays_per_frame)
-            vi = pmc.get("SQ_INSTS_VALU")
-            ach = vi * share / (kms[dom] * 1e-3) / 1e9 if vi else None
-            out["roofline"] = {"bound": "valu_issue", "kernel": dom, "achieved": round(ach, 1) if ach else None, "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instructions/s",
-                               "frac": round(ach / VALU_ISSUE_PEAK_G, 4) if ach else None, "traffic": pmc.get("hbm_bytes_per_launch") * share if pmc.get("hbm_bytes_per_launch") else None,
+            scaled = dict(pmc)
+            if pmc.get("SQ_INSTS_VALU"):
+                scaled["SQ_INSTS_VALU"] = pmc["SQ_INSTS_VALU"] * share
+            scaled["sq"] = {k: v * share for k, v in pmc.get("sq", {}).items()}
+            ir = issue_roofline(scaled, kms[dom])
+            out["roofline"] = {"bound": "valu_issue", "kernel": dom, "achieved": ir.get("achieved"), "peak": ir.get("peak"), "unit": "G wave-instructions/s",
+                               "frac": ir.get("frac"), "traffic": pmc.get("hbm_bytes_per_launch") * share if pmc.get("hbm_bytes_per_launch") else None,
+                               "valu_f64_share": ir.get("valu_f64_share"), "salu_issue": ir.get("salu_issue"), "counters_stale": counters_stale(),
                                "kernel_ms": round(kms[dom], 4), "rays_per_launch": int(my_rays), "share_of_frame": round(share, 4),
                                "note": "rank 0's tile share of a frame, one launch in flight, HIP events on its stream; instruction and traffic counts = the one-GPU frame's "
                                        "PMC figures x this rank's share of the rays (the counters were collected on the full frame)"}
@@ -351,25 +428,33 @@ def bench_c2(args, D, torch, rta, W):
     pmc = read_traffic(dom)
     valu_insts = pmc.get("SQ_INSTS_VALU")                  # wave-level VALU instructions per launch (rocprofv3 --pmc pass)
     cycles = pmc.get("kernel_cycles")                      # GRBM_GUI_ACTIVE per launch / 8 XCDs
-    if valu_insts:
-        ach_issue = valu_insts / (dom_ms * 1e-3) / 1e9     # G wave-instructions/s against the live kernel time
-        frac_issue = ach_issue / VALU_ISSUE_PEAK_G
-        frac_issue_measured_clock = (valu_insts * 4.0 / N_SIMD / cycles) if cycles else None
-    else:
-        ach_issue = frac_issue = frac_issue_measured_clock = None
-    roofline = {"bound": "valu_issue", "kernel": dom, "achieved": round(ach_issue, 1) if ach_issue else None, "peak": VALU_ISSUE_PEAK_G,
-                "unit": "G wave-instructions/s", "frac": round(frac_issue, 4) if frac_issue else None,
-                "frac_at_measured_clock": round(frac_issue_measured_clock, 4) if frac_issue_measured_clock else None,
+    ir = issue_roofline(pmc, dom_ms)
+    # USEFUL work: SURVEY 8(d)'s algorithmic weights on this traversal's own counts -- 40 flop per box test, 85 per triangle test (cull records and
+    # exact confirmations alike) -- against the FP64 vector peak.  What the issue fraction has beyond this is overhead (profiles/README.md itemises it).
+    useful_flops_per_ray = 40.0 * nodes_per_ray + 85.0 * (prims_per_ray + exact_per_ray)
+    useful_tf = useful_flops_per_ray * rays_dom / (dom_ms * 1e-3) / 1e12
+    roofline = {"bound": "valu_issue", "kernel": dom, "achieved": ir.get("achieved"), "peak": ir.get("peak"),
+                "unit": "G wave-instructions/s", "frac": ir.get("frac"),
+                "valu_f64_share": ir.get("valu_f64_share"), "valu_other_share": ir.get("valu_other_share"), "peak_definition": ir.get("peak_definition"),
+                "frac_if_all_4_cycles": ir.get("frac_if_all_4_cycles"), "frac_if_all_2_cycles": ir.get("frac_if_all_2_cycles"),
+                "salu_issue": ir.get("salu_issue"),
+                "useful": {"frac": round(useful_tf / FP64_VALU_PEAK_TF, 4), "achieved_tflops": round(useful_tf, 2), "peak_tflops": FP64_VALU_PEAK_TF,
+                           "flops_per_ray": round(useful_flops_per_ray, 1),
+                           "definition": "SURVEY 8(d) weights on the counts of this traversal: (40 x box tests + 85 x (cull records + confirmations)) x rays / kernel time / 78.6 TF FP64 vector"},
+                "counters_stale": counters_stale(), "counters_file": os.path.relpath(traffic_file(), ROOT),
                 "traffic": pmc.get("hbm_bytes_per_launch"),
                 "kernel_ms": round(dom_ms, 4), "kernel_ms_source": "HIP events on the kernel's stream, one frame in flight, %d launches" % n_one,
                 "rays_per_launch": int(rays_dom), "valu_wave_insts_per_launch": valu_insts,
                 "valu_lane_insts_per_ray": round(valu_insts * 64.0 / rays_dom, 1) if valu_insts else None,
-                "note": "the walk is bound by VALU issue (FP32 box tests, FP64 cull and confirmation + the integer work around them), not by HBM: the scene (0.2 GB) is L2 / "
-                        "Infinity-Cache resident.  peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; SQ_INSTS_VALU from profiles/r02_traffic.json",
+                "frac_at_measured_clock_all_4_cycles": round(valu_insts * 4.0 / N_SIMD / cycles, 4) if (valu_insts and cycles) else None,
+                "note": "the walk is bound by instruction issue (FP32 box tests, FP64 cull and confirmation + the integer, move and select work around them), not by HBM: the "
+                        "scene (0.2 GB) is L2 / Infinity-Cache resident.  Counters: rocprofv3 --pmc passes of this command kept in profiles/ (counters_stale says whether "
+                        "they are of the library timed here); time: live",
                 "hbm": {"achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_gbs / HBM_PEAK_GBS, 4),
                         "bytes_per_ray": round(bytes_per_ray, 1), "bytes_definition": "packet: node / record bytes once per wave that needs them",
                         "lane_bytes_per_ray": round(lane_bytes_per_ray, 1), "lane_bytes_definition": "what 64 independent rays would fetch (served by LDS / SGPR broadcasts)"},
-                "valu_fp64": {"achieved_tflops": round(tf, 2), "peak_tflops": FP64_VALU_PEAK_TF, "frac": round(tf / FP64_VALU_PEAK_TF, 4), "flops_per_ray": round(flops_per_ray, 1)},
+                "valu_fp64": {"achieved_tflops": round(tf, 2), "peak_tflops": FP64_VALU_PEAK_TF, "frac": round(tf / FP64_VALU_PEAK_TF, 4), "flops_per_ray": round(flops_per_ray, 1),
+                              "definition": "the FP64 flops this implementation issues (45 per cull record, 150 per confirmation; its box tests run in FP32)"},
                 "box_tests_per_ray": round(nodes_per_ray, 2), "cull_records_per_ray": round(prims_per_ray, 2), "exact_tests_per_ray": round(exact_per_ray, 3),
                 "wave_box_fetches_per_ray": round(wave_boxes_per_ray, 3), "wave_record_fetches_per_ray": round(wave_recs_per_ray, 3),
                 "all_kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
@@ -443,10 +528,11 @@ def bench_c2(args, D, torch, rta, W):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def other_config(name, args, D, torch, rta, W, ctx, short):
-    """C3 / C4 / C5 on their stated geometry at 1080p.  `short`: a cut-down run for config.other_configs of the default
-    line.  N > 1: C3 splits the samples (all-reduce of the un-clamped sums), C5 the photons (all-reduce of the per-hit-
-    point statistics), C4 the rows (all-gather)."""
+def other_config(name, args, D, torch, rta, W, ctx, short, once=False):
+    """C3 / C4 / C5 on their stated geometry at 1080p.  `short`: a cut-down, extrapolated run; otherwise BASELINE's sizes (1024 spp, 256 spp,
+    10 M photons per pass) unless --spp / --photons say otherwise.  once: one timed repetition (the default line's other_configs).
+    N > 1: C3 splits the samples (all-reduce of the un-clamped sums), C5 the photons (all-reduce of the per-hit-point statistics), C4 the
+    rows (all-gather)."""
     from ray_tracing_amd import parallel
     rank, world, dev = D.rank, D.world, D.dev
     res = {}
@@ -455,7 +541,7 @@ def other_config(name, args, D, torch, rta, W, ctx, short):
         cam = rta.Camera(**W.C3_CAMERA)
         n = cam.width * cam.height
         spp_total = 1024
-        spp_run = args.spp or (2 if short else 8)
+        spp_run = args.spp or (2 if short else spp_total)
         rgb = torch.zeros(n * 3, dtype=torch.float64, device=dev)
         s0, cnt = parallel.sample_shard(spp_run, rank, world)
         p = rta.Params(background=(200, 200, 200), spp=spp_total, lens_radius=0.1, sample_first=s0, sample_count=max(cnt, 1), seed=1)
@@ -469,14 +555,18 @@ def other_config(name, args, D, torch, rta, W, ctx, short):
                     h = rgb.cpu(); D.dist.all_reduce(h); rgb.copy_(h)
                 else:
                     D.dist.all_reduce(rgb)
-        step(); torch.cuda.synchronize()
-        rays = D.reduce(last_rays(rta, raw)[0] if cnt else 0, "sum")
-        reps = 1 if short else max(1, args.steps)
+        reps = 1 if (short or once or spp_run >= 256) else max(1, args.steps)
+        if not (once and not short):          # (a full-size frame inside the default line is rendered once: its own first call is the timed one)
+            step(); torch.cuda.synchronize()
+        else:
+            p1 = rta.Params(background=(200, 200, 200), spp=spp_total, lens_radius=0.1, sample_first=0, sample_count=1, seed=1)
+            rta.check(rta.hip.rt_hip_render_focusing_dev(raw, cam.raw, p1, C.c_void_p(rgb.data_ptr()), None)); torch.cuda.synchronize()     # workspace allocation
         D.barrier(); t = time.perf_counter()
         for _ in range(reps):
             step()
         D.barrier()
         dt = D.reduce((time.perf_counter() - t) / reps, "max")
+        rays = D.reduce(last_rays(rta, raw)[0] if cnt else 0, "sum")
         res = {"workload": "C3: Layout3_Icosahedron, depth of field (Camera.h:171-199) %dx%d, 10x10 area light (100 shadow rays per lens sample), lens radius 0.1" % (cam.width, cam.height),
                "samples_per_pixel_timed": spp_run, "rays": int(rays), "s_per_step": round(dt, 5), "Mrays_per_s": round(rays / dt / 1e6, 1),
                "s_per_frame_at_1024spp": round(dt / spp_run * spp_total, 2), "extrapolated": spp_run != spp_total,
@@ -489,7 +579,7 @@ def other_config(name, args, D, torch, rta, W, ctx, short):
         assert (cam.width, cam.height) == (1920, 1080)
         n = cam.width * cam.height
         spp_total = 256
-        spp_run = args.spp or (4 if short else 16)
+        spp_run = args.spp or (4 if short else spp_total)
         aa = rta.AaParams(oversample_times=spp_run, depth_grad_threshold=-1.0)       # every pixel re-sampled: the fixed-spp jittered render
         first, count = parallel.row_shard(cam.height, cam.width, rank, world)
         p = rta.Params(background=(30, 30, 30), seed=1, pixel_first=first, pixel_count=count)
@@ -501,14 +591,18 @@ def other_config(name, args, D, torch, rta, W, ctx, short):
                 rta.check(rta.hip.rt_hip_render_antialiasing_dev(raw, cam.raw, p, aa, C.c_void_p(rgb.data_ptr()), None, None))
             if world > 1 and not D.rehearsal:
                 parallel.gather_rows(rgb.view(-1, 3)[:count], cam.height, cam.width, 3)
-        step(); torch.cuda.synchronize()
-        rays = D.reduce(last_rays(rta, raw)[0] if count else 0, "sum")
-        reps = 1 if short else max(1, min(args.steps, 5))
+        reps = 1 if (short or once or spp_run >= 64) else max(1, min(args.steps, 5))
+        if not (once and not short):
+            step(); torch.cuda.synchronize()
+        else:
+            aa1 = rta.AaParams(oversample_times=1, depth_grad_threshold=-1.0)
+            rta.check(rta.hip.rt_hip_render_antialiasing_dev(raw, cam.raw, p, aa1, C.c_void_p(rgb.data_ptr()), None, None)); torch.cuda.synchronize()   # first-call set-up
         D.barrier(); t = time.perf_counter()
         for _ in range(reps):
             step()
         D.barrier()
         dt = D.reduce((time.perf_counter() - t) / reps, "max")
+        rays = D.reduce(last_rays(rta, raw)[0] if count else 0, "sum")
         res = {"workload": "C4: Layout2_WallAndPaper (Bezier patch + WallLight.obj, %d objects) %dx%d depth 2, pixel-jittered (r0 0.007), every pixel re-sampled" % (g.num_objects, cam.width, cam.height),
                "samples_per_pixel_timed": spp_run, "rays": int(rays), "s_per_step": round(dt, 5), "Mrays_per_s": round(rays / dt / 1e6, 1),
                "s_per_frame_at_256spp": round(dt / spp_run * spp_total, 2), "extrapolated": spp_run != spp_total,
@@ -518,14 +612,14 @@ def other_config(name, args, D, torch, rta, W, ctx, short):
         g = W.build_wine(W.product_stage, cups="layout", light="area5").sides[0][0]
         assert g.num_objects == 24
         cam = rta.Camera(**W.C5_CAMERA)
-        photon_num = args.photons or (20000 if short else 100000)                   # x 25 light samples per pass (full config: 400000 -> 10 M)
+        photon_num = args.photons or (20000 if short else 400000)                   # x 25 light samples per pass (the config: 400000 -> 10 M)
         t = time.perf_counter()
         pm = rta.PhotonMap(ctx, g, cam, photon_num=photon_num, times=64, background=(10, 10, 10), seed=1)
         torch.cuda.synchronize()
         t_eye = time.perf_counter() - t
         eye_rays = last_rays(rta, g.device(ctx))[0]
         info = pm.info()
-        passes = 1 if short else max(1, min(args.steps, 4))
+        passes = 1 if (short or once) else max(1, min(args.steps, 4))
         D.barrier(); t = time.perf_counter()
         for k in range(passes):
             if world > 1 and not D.rehearsal:
@@ -544,46 +638,38 @@ def other_config(name, args, D, torch, rta, W, ctx, short):
         kernel = "k_ppm_trace"
     pmc = read_traffic(kernel + ":" + name) or read_traffic(kernel)
     if pmc.get("SQ_INSTS_VALU") and pmc.get("kernel_cycles"):
+        # (both figures from the same profiled run: instructions and GRBM cycles of the kernel; the mix weights the cycles per instruction)
+        share = pmc.get("valu_f64_share")
+        cyc = (4.0 * share + 2.0 * (1.0 - share)) if share is not None else 4.0
         res["dominant_kernel"] = kernel
-        res["valu_issue_frac"] = round(pmc["SQ_INSTS_VALU"] * 4.0 / N_SIMD / pmc["kernel_cycles"], 4)
+        res["valu_issue_frac"] = round(pmc["SQ_INSTS_VALU"] * cyc / N_SIMD / pmc["kernel_cycles"], 4)
+        res["valu_f64_share"] = round(share, 4) if share is not None else None
+        res["valu_issue_frac_if_all_4_cycles"] = round(pmc["SQ_INSTS_VALU"] * 4.0 / N_SIMD / pmc["kernel_cycles"], 4)
+    res["_scene"] = g
     return res
 
 
-def cpu_sample(name, W, rows=2):
-    """the oracle on a bounded sample of C3 / C4 / C5 (a few seconds): a couple of image rows of the same frame"""
+def config_checks(name, rta, ctx, g, threads):
+    """parity of config `name` against the oracle on a bounded sample of the same frame, and the oracle's rate on that sample (the config's
+    cpu_baseline): tests/config_parity.py, the comparisons the GPU tests assert on.  Outside every timed region."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import config_parity as cp
     import scenes
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     if name == "C3":
         _, o = scenes.build_icosahedron(material="plastic", light="area10", gpu=False)
-        cam = scenes.oracle_camera(W.C3_CAMERA)
-        w = 1920
-        lens = 1
-        t = time.perf_counter()
-        o.render_focusing(cam, 0.1, lens, background=(200, 200, 200), seed=1, first=(540 - rows // 2) * w, count=rows * w, threads=threads)
-        dt = time.perf_counter() - t
-        rays = rows * w * 101 * lens
-        what = "%d centre rows x %d lens sample(s) of the C3 frame (camera ray + 100 shadow rays each)" % (rows, lens)
+        par, cpu = cp.c3_rows(rta, ctx, g, o, rows=tuple(range(2, 1080, 8)), spp=2, seed=1, threads=threads)
     elif name == "C4":
         _, o = scenes.build_paper(gpu=False)
-        cam = scenes.oracle_camera(W.C4_CAMERA)
-        w = 1920
-        t = time.perf_counter()
-        _, _, cnt = o.render_whitted(cam, background=(30, 30, 30), first=540 * w, count=rows * w, threads=threads, counters=True)
-        dt = time.perf_counter() - t
-        rays = int(cnt[0])
-        what = "%d centre rows x 1 sample of the C4 frame, depth 2" % rows
+        par, cpu = cp.c4_rows(rta, ctx, g, o, rows=tuple(range(100, 1000, 28)), threads=threads)
     else:
         _, o = scenes.build_wine(gpu=False, cups="layout", light="area5")
-        cam = scenes.oracle_camera(W.C5_CAMERA)
-        w = 1920
-        t = time.perf_counter()
-        npx = w // 4 if rows <= 1 else rows * w
-        _, _, cnt = o.render_whitted(cam, background=(10, 10, 10), first=540 * w, count=npx, threads=threads, counters=True)
-        dt = time.perf_counter() - t
-        rays = int(cnt[0])
-        what = "%s of the C5 eye pass (depth 8, 25 shadow rays per hit), Whitted part only" % ("a quarter of the centre row" if rows <= 1 else "%d centre rows" % rows)
-    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port", "sample": "%s: %d rays, %.2f s, oracle/rt_oracle.c with OpenMP" % (what, rays, dt)}
+        par, cpu = cp.c5_eye_rows(rta, ctx, g, o, rows=(300, 420, 540, 650, 760, 880), threads=threads)
+        ppm, cpu2 = cp.c5_photon_map(rta, ctx, g, o, res=24, photon_num=1500, passes=2)
+        par = {"eye_pass": par, "photon_map": ppm}
+        cpu = {"rays": cpu["rays"] + cpu2["rays"], "seconds": cpu["seconds"] + cpu2["seconds"]}
+    base = {"value": round(cpu["rays"] / max(cpu["seconds"], 1e-9) / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "the parity sample of this config (parity.sample): %d rays, %.2f s, oracle/rt_oracle.c with OpenMP" % (cpu["rays"], cpu["seconds"])}
+    return par, base
 
 
 def main():
@@ -599,6 +685,7 @@ def main():
     import torch
     import ray_tracing_amd as rta
     from ray_tracing_amd import workloads as W
+    W.set_asset_dir(os.path.join(ROOT, "tests", "golden", "assets"))      # the layouts' meshes: the repository's data fixtures
 
     D = Dist(args, torch)
     if D.world != args.gpus:
@@ -607,29 +694,38 @@ def main():
         out = bench_c2(args, D, torch, rta, W)
         if out is not None and D.world == 1 and not args.emulate_world and not args.no_extras:
             ctx = rta.Context(D.local_rank)
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             others = {}
             for name in ("C3", "C4", "C5"):
                 try:
-                    others[name] = other_config(name, args, D, torch, rta, W, ctx, short=True)
+                    others[name] = other_config(name, args, D, torch, rta, W, ctx, short=(args.others == "short"), once=True)
+                    g = others[name].pop("_scene")
                     if not args.no_cpu_baseline:
-                        others[name]["cpu_baseline"] = cpu_sample(name, W, rows=540 if name == "C3" else 1)
+                        others[name]["parity"], others[name]["cpu_baseline"] = config_checks(name, rta, ctx, g, threads)
+                    del g
                 except Exception as e:          # a secondary figure must not cost the headline line
                     others[name] = {"error": repr(e)}
             out["config"]["other_configs"] = others
     else:
         ctx = rta.Context(D.local_rank)
         res = other_config(args.config, args, D, torch, rta, W, ctx, short=False)
+        g = res.pop("_scene")
         out = None
         if D.rank == 0:
             out = {"metric": "Mrays/sec (primary+secondary)", "value": res["Mrays_per_s"], "unit": "Mrays/s", "n_gpus": D.world, "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": round(res["s_per_step"] * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                    "dtype": "f64", "data": "synthetic", "config": res}
             pmc_k = res.get("dominant_kernel")
-            out["roofline"] = {"bound": "valu_issue", "kernel": pmc_k, "frac": res.get("valu_issue_frac"), "peak": VALU_ISSUE_PEAK_G, "unit": "G wave-instructions/s",
-                               "achieved": round(res["valu_issue_frac"] * VALU_ISSUE_PEAK_G, 1) if res.get("valu_issue_frac") else None, "traffic": None,
-                               "note": "from the rocprofv3 --pmc passes of this config kept in profiles/r02_traffic.json (SQ_INSTS_VALU x 4 / 1024 SIMDs / kernel cycles)"}
+            share = res.get("valu_f64_share")
+            peak = valu_peak_g(share) if share is not None else VALU_ISSUE_PEAK_ALL_F64_G
+            out["roofline"] = {"bound": "valu_issue", "kernel": pmc_k, "frac": res.get("valu_issue_frac"), "peak": round(peak, 1), "unit": "G wave-instructions/s",
+                               "achieved": round(res["valu_issue_frac"] * peak, 1) if res.get("valu_issue_frac") else None, "traffic": None,
+                               "valu_f64_share": share, "counters_stale": counters_stale(),
+                               "note": "from the rocprofv3 --pmc passes of this config kept in %s: SQ_INSTS_VALU x (4 f64_share + 2 (1 - f64_share)) cycles / 1024 SIMDs / "
+                                       "the kernel's GRBM cycles in the same profiled run" % os.path.relpath(traffic_file(), ROOT)}
             if not args.no_cpu_baseline and D.world == 1:
-                out["cpu_baseline"] = cpu_sample(args.config, W, rows={"C3": 1080, "C4": 64, "C5": 12}[args.config])      # ~10 s of host work each
+                threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+                out["parity"], out["cpu_baseline"] = config_checks(args.config, rta, ctx, g, threads)
     if D.rank == 0 and out is not None:
         print(json.dumps(out), flush=True)
     D.finish()

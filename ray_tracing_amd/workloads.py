@@ -10,10 +10,30 @@ import os
 
 import numpy as np
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-ASSETS = os.path.join(os.path.dirname(HERE), "tests", "golden", "assets")      # the repo's data fixtures (meshes of the reference's layouts)
-ICOSA_OBJ = os.path.join(ASSETS, "Icosahedron_Triangle.obj")     # the reference's ObjFiles/Icosahedron_Triangle.obj (a mesh: data)
-WALL_LIGHT_OBJ = os.path.join(ASSETS, "WallLight.obj")           # the reference's ObjFiles/WallLight.obj, 11,576 faces (Layout.h:125)
+# The meshes of the reference's layouts (ObjFiles/Icosahedron_Triangle.obj; ObjFiles/WallLight.obj, 11,576 faces, Layout.h:125) are data the
+# CALLER brings: the package ships none and reaches into no other directory.  bench.py and the tests point this at the repository's fixtures
+# (tests/golden/assets) with set_asset_dir(); a user points it at the reference's ObjFiles/.
+_ASSET_DIR = os.environ.get("RT_ASSET_DIR")
+
+
+def set_asset_dir(path):
+    """the directory that holds Icosahedron_Triangle.obj and WallLight.obj for the builders below"""
+    global _ASSET_DIR
+    _ASSET_DIR = path
+
+
+def asset(name):
+    if not _ASSET_DIR:
+        raise RuntimeError("workloads: no asset directory (set_asset_dir(<dir with %s>) or RT_ASSET_DIR): the layouts' meshes are the caller's data" % name)
+    return os.path.join(_ASSET_DIR, name)
+
+
+def icosa_obj():
+    return asset("Icosahedron_Triangle.obj")
+
+
+def wall_light_obj():
+    return asset("WallLight.obj")
 
 
 class Stage:
@@ -54,7 +74,7 @@ def build_icosahedron(make_stage, material="plastic", light="point_area", bsp=Tr
     if planes:      # planes=False: primary rays can leave the scene
         P.call("add_plane", (0, 0, 0), (0, 0, 1), mat=plastic, colour=(255, 255, 255))
         P.call("add_plane", (10, 0, 0), (-1, 0, 0), mat=plastic, colour=(0, 0, 0))
-    P.call("read_obj_triangle", ICOSA_OBJ, (0, -1, 0), 0.0015, mat=P.mat(material), colour=(241, 46, 24))
+    P.call("read_obj_triangle", icosa_obj(), (0, -1, 0), 0.0015, mat=P.mat(material), colour=(241, 46, 24))
     if extra_sphere:
         P.call("add_sphere", (0.3, 0.6, 0.5), 0.5, mat=P.mat("glass"), colour=(161, 143, 81))
         P.call("add_sphere", (-1.0, -2.2, 0.35), 0.35, mat=P.mat("mirror"), colour=(255, 255, 255))
@@ -179,9 +199,9 @@ def build_paper(make_stage, bsp=True, mesh="walllight", material="rubber"):
     P.call("add_plane", (20, 0, 0), (-1, 0, 0), mat=P.mat("rubber"), colour=(120, 120, 120))
     P.call("add_bezier", PAPER_CTRL, PAPER_CENTER, mat=P.mat(material), colour=(255, 255, 255))
     if mesh == "walllight":
-        P.call("read_obj_triangle", WALL_LIGHT_OBJ, (20, 13, 20), 0.7, mat=P.mat("metal"), colour=(50, 50, 60))
+        P.call("read_obj_triangle", wall_light_obj(), (20, 13, 20), 0.7, mat=P.mat("metal"), colour=(50, 50, 60))
     elif mesh == "icosahedron" or mesh is True:
-        P.call("read_obj_triangle", ICOSA_OBJ, (18.5, 13, 20), 0.004, mat=P.mat("metal"), colour=(50, 50, 60))
+        P.call("read_obj_triangle", icosa_obj(), (18.5, 13, 20), 0.004, mat=P.mat("metal"), colour=(50, 50, 60))
     P.call("add_parallel_light", (1, -1, -1), 2.0)
     if bsp:
         P.call("construct_bsp")
@@ -252,7 +272,7 @@ def build_room(make_stage, mirror=True):
     quad((-12, 5, 0), (2, 5, 0), (2, 5, 8), (-12, 5, 8), plastic, (200, 200, 200))               # wall, left of the window
     quad((6, 5, 0), (30, 5, 0), (30, 5, 8), (6, 5, 8), plastic, (200, 200, 200))                 # wall, right of the window
     quad((2, 5, 0), (6, 5, 0), (6, 5, 1), (2, 5, 1), plastic, (200, 200, 200))                   # sill
-    P.call("read_obj_triangle", ICOSA_OBJ, (9, -2, 0), 0.003, mat=P.mat("metal" if mirror else "plastic"), colour=(241, 46, 24))
+    P.call("read_obj_triangle", icosa_obj(), (9, -2, 0), 0.003, mat=P.mat("metal" if mirror else "plastic"), colour=(241, 46, 24))
     P.call("construct_bsp")
     P.call("add_area_light", (-10, 20, 20), 2.0, 10.0, 2)
     return P

@@ -1,11 +1,19 @@
 """Scene builders of the tests: the workloads of ray_tracing_amd/workloads.py built on BOTH sides -- the product scene
 (ray_tracing_amd.Scene, the C++ host layer) and the checker's (tests/oracle_bind.OracleScene) -- with the same calls in
 the same order, so that primitive ids agree.  Either side may be skipped (gpu=False / oracle=False)."""
+import os
+
 import numpy as np
 
 from ray_tracing_amd import workloads as W
 from ray_tracing_amd.workloads import (C1_CAMERA, C2_CAMERA, C3_CAMERA, C4_CAMERA, C5_CAMERA, ROOM_CAMERA, TEX_CAMERA, PAPER_CTRL, PAPER_CENTER,  # noqa: F401
-                                       CUP2_PROFILES, APPLE_PROFILE, ICOSA_OBJ, WALL_LIGHT_OBJ, fnv_hash_ids, synth_texture, heightfield_triangles)
+                                       CUP2_PROFILES, APPLE_PROFILE, fnv_hash_ids, synth_texture, heightfield_triangles)
+
+# the meshes of the reference's layouts are test data: kept under tests/golden/assets, handed to the workload builders from here
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets")
+W.set_asset_dir(ASSETS)
+ICOSA_OBJ = os.path.join(ASSETS, "Icosahedron_Triangle.obj")     # the reference's ObjFiles/Icosahedron_Triangle.obj (a mesh: data)
+WALL_LIGHT_OBJ = os.path.join(ASSETS, "WallLight.obj")           # the reference's ObjFiles/WallLight.obj, 11,576 faces (Layout.h:125)
 
 
 def _stage(gpu, oracle):

@@ -6,6 +6,7 @@ import zlib
 import numpy as np
 import pytest
 
+import parity_log as pl
 import scenes
 
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_r01.npz"))
@@ -69,12 +70,12 @@ def test_gpu_reproduces_golden_aa_textures(ctx):
     cam = rta.Camera(**AA_CAM)
     cam.set_seed(3)
     cam.render_raytracer_antialiasing(ctx, g, background=(200, 200, 200), oversample_times=8)
-    assert (cam.edge_mask() == GB["aa_mask"]).mean() >= 1 - 1e-3
     ok = cam.edge_mask() == GB["aa_mask"]
+    pl.allow("aa mask_mismatches", (~ok).sum(), ok.size, bar_count=1, cause="a Laplacian within rounding of its threshold")
     assert (np.abs(cam.rgb() - GB["aa_rgb"]) / np.maximum(1.0, np.abs(GB["aa_rgb"])))[ok].max() < 1e-3
     cam.render_focusing_antialiasing(ctx, g, 0.1, background=(200, 200, 200), spp=3, oversample_times=4)
     ok = cam.edge_mask() == GB["aa_focus_mask"]
-    assert ok.mean() >= 1 - 1e-3
+    pl.allow("focusing aa mask_mismatches", (~ok).sum(), ok.size, bar_count=1, cause="a Laplacian within rounding of its threshold")
     assert (np.abs(cam.rgb() - GB["aa_focus_rgb"]) / np.maximum(1.0, np.abs(GB["aa_focus_rgb"])))[ok].max() < 1e-3
     gt, _ = scenes.build_textured(oracle=False)
     camt = rta.Camera(**TEX_CAM)
@@ -82,7 +83,7 @@ def test_gpu_reproduces_golden_aa_textures(ctx):
     camt.render_raytracer(ctx, gt, background=(20, 30, 40))
     assert (camt.prim_id() == GB["tex_ids"]).all()
     err = (np.abs(camt.rgb() - GB["tex_rgb"]) / np.maximum(1.0, np.abs(GB["tex_rgb"]))).max(axis=1)
-    assert (err >= 1e-3).mean() <= 1e-3                      # texel-boundary pixels
+    pl.allow("texel_boundary_pixels", (err >= 1e-3).sum(), err.size, bar_count=11, cause="a hit within an ulp of a texel boundary reads the neighbouring texel (DESIGN 4.6)")
 
 
 @pytest.mark.gpu
@@ -116,7 +117,7 @@ def test_gpu_reproduces_golden(ctx):
     for rec in (1, 0):
         h5 = g5.first_inter_pt(ctx, rays5, use_tree=False, record=bool(rec))
         ids5 = G["c5_ids_rec%d" % rec]
-        assert (h5["prim_id"] != ids5).mean() <= 1e-4
+        pl.allow("c5 rec%d id_mismatches" % rec, (h5["prim_id"] != ids5).sum(), len(ids5), bar=1e-4, cause="t-ties")
         ok = (ids5 >= 0) & (h5["prim_id"] == ids5)
         assert np.abs(h5["t"][ok] - G["c5_t_rec%d" % rec][ok]).max() < 1e-6
     # photon map
@@ -128,9 +129,10 @@ def test_gpu_reproduces_golden(ctx):
         ref = G["ppm_pass%d_key_R_N" % t]
         got = pm.hitpoints()[:, [0, 1, 9, 10]]
         assert got.shape == ref.shape and (got[:, :2] == ref[:, :2]).all()
-        assert (np.abs(got[:, 3] - ref[:, 3]) > 1e-9).mean() < 1e-3
+        pl.allow("ppm pass %d: hit points with different N" % t, (np.abs(got[:, 3] - ref[:, 3]) > 1e-9).sum(), len(ref), bar=1e-3, cause="photons on the rim of a gather disc")
     d = np.abs(pm.picture() - G["ppm_picture"].astype(np.float64))
-    assert d.max() <= 2 and (d > 0).mean() < 5e-3
+    assert d.max() <= 2
+    pl.allow("ppm picture: pixels differing", (d.max(axis=1) > 0).sum(), d.shape[0], bar=1e-3, cause="Vec3b(tau) truncation of values within rounding of an integer")
 
 
 # ---- round 2: the configs on their stated geometry, and the drivers the Wine / Room layouts call (golden_r02.npz) ----
@@ -188,7 +190,7 @@ def test_gpu_reproduces_golden_r02(ctx):
     g4, _ = scenes.build_paper(oracle=False)
     rays4, _, _ = ob.OracleScene(0.0).camera_rays(scenes.oracle_camera(dict(scenes.C4_CAMERA, res=32)))
     h4 = g4.first_inter_pt(ctx, rays4, use_tree=True)
-    assert (h4["prim_id"] != GC["c4_ids"]).mean() <= 1e-4
+    pl.allow("c4 id_mismatches", (h4["prim_id"] != GC["c4_ids"]).sum(), len(GC["c4_ids"]), bar=1e-4, cause="t-ties")
     ok = (GC["c4_ids"] >= 0) & (h4["prim_id"] == GC["c4_ids"])
     assert np.abs(h4["t"][ok] - GC["c4_t"][ok]).max() < 1e-6
     par = ok & (GC["c4_ids"] == 1)
@@ -197,21 +199,22 @@ def test_gpu_reproduces_golden_r02(ctx):
     g5, _ = scenes.build_wine(oracle=False, cups="layout", light="area5")
     rays5, _, _ = ob.OracleScene(0.0).camera_rays(scenes.oracle_camera(dict(scenes.C5_CAMERA, res=12)))
     h5 = g5.first_inter_pt(ctx, rays5, use_tree=False, record=True)
-    assert (h5["prim_id"] != GC["c5_ids"]).mean() <= 1e-4
+    pl.allow("c5 id_mismatches", (h5["prim_id"] != GC["c5_ids"]).sum(), len(GC["c5_ids"]), bar=1e-4, cause="t-ties")
     ok = (GC["c5_ids"] >= 0) & (h5["prim_id"] == GC["c5_ids"])
     assert np.abs(h5["t"][ok] - GC["c5_t"][ok]).max() < 1e-6
     # Render_PhotonMapper_Antialiasing
     gp, _ = scenes.build_icosahedron(material="plastic", light="point_area", extra_sphere=True, oracle=False)
     pm = rta.PhotonMap(ctx, gp, rta.Camera(**R02_PPM_CAM), photon_num=8000, times=2, background=(10, 10, 10), seed=6, aa=rta.AaParams(oversample_times=4))
-    assert (pm.edge_mask() != GC["ppm_aa_mask"]).mean() <= 1e-3
+    pl.allow("ppm aa mask_mismatches", (pm.edge_mask() != GC["ppm_aa_mask"]).sum(), GC["ppm_aa_mask"].size, bar_count=1, cause="a Laplacian within rounding of its threshold")
     for t in range(2):
         pm.run_pass(t)
         ref = GC["ppm_aa_pass%d_key_R_N" % t]
         got = pm.hitpoints()[:, [0, 1, 9, 10]]
         assert got.shape == ref.shape and (got[:, :2] == ref[:, :2]).all()
-        assert (np.abs(got[:, 3] - ref[:, 3]) > 1e-9).mean() < 1e-3
+        pl.allow("ppm aa pass %d: hit points with different N" % t, (np.abs(got[:, 3] - ref[:, 3]) > 1e-9).sum(), len(ref), bar=1e-3, cause="photons on the rim of a gather disc")
     d = np.abs(pm.picture() - GC["ppm_aa_picture"].astype(np.float64))
-    assert d.max() <= 2 and (d > 0).mean() < 1e-2
+    assert d.max() <= 2
+    pl.allow("ppm aa picture: pixels differing", (d.max(axis=1) > 0).sum(), d.shape[0], bar=1e-3, cause="round(sum / oversampleTimes) and Vec3b(tau) truncation")
     # Render_RayTracer_GodRay_Antialiasing
     gr, _ = scenes.build_room(oracle=False)
     gg = rta.GodRay(ctx, gr, (155, 155, 50), seed=9)
@@ -219,6 +222,6 @@ def test_gpu_reproduces_golden_r02(ctx):
     gg.photon_mapping_pass()
     rgb, mask = gg.render_antialiasing(rta.Camera(**R02_ROOM_CAM), aa=rta.AaParams(oversample_times=4), background=(20, 20, 30))
     agree = mask == GC["godray_aa_mask"]
-    assert (~agree).mean() <= 1e-3
+    pl.allow("godray aa mask_mismatches", (~agree).sum(), agree.size, bar_count=1, cause="a Laplacian within rounding of its threshold")
     ref = GC["godray_aa_rgb"]
     assert (np.abs(rgb - ref) / np.maximum(1.0, np.abs(ref)))[agree].max() < 1e-3

@@ -4,6 +4,7 @@ Tolerances: edge masks identical except where a Laplacian lies within rounding o
 import numpy as np
 import pytest
 
+import parity_log as pl
 import scenes
 
 pytestmark = pytest.mark.gpu
@@ -13,15 +14,18 @@ def _rel_err(a, b):
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
 
+MASK_FLIPS = 1             # 2 x + 1 of the count observed on the GPU box (profiles/r03_parity_counts.json: 0 everywhere)
+
+
 def _compare(cam, rgb_ref, mask_ref, what, min_edges):
     rgb, mask = cam.rgb(), cam.edge_mask()
     agree = mask == mask_ref
     print("%s: %d masked pixels of %d (oracle %d), mask mismatches %d" % (what, int(mask.sum()), mask.size, int(mask_ref.sum()), int((~agree).sum())))
     assert mask_ref.sum() >= min_edges and (mask_ref == 0).sum() >= min_edges      # both branches are exercised
-    assert (~agree).mean() <= 1e-3
+    pl.allow("mask_mismatches: " + what, (~agree).sum(), mask.size, bar_count=MASK_FLIPS, cause="a Laplacian within rounding of its threshold")
     err = _rel_err(rgb, rgb_ref)[agree]
     print("%s: max rel err %.3g" % (what, err.max()))
-    assert err.max() < 1e-3
+    pl.value("max_rel_colour_err: " + what, err.max(), 1e-3)
 
 
 @pytest.mark.parametrize("material,light,depth", [("metal", "point_area", 2), ("plastic", "area3", 1)])
@@ -178,25 +182,27 @@ def test_photon_mapper_antialiasing_parity(ctx):
     gm = rta.PhotonMap(ctx, g, rta.Camera(**cam_args), photon_num=20000, times=2, background=(10, 10, 10), seed=6, aa=rta.AaParams(oversample_times=os_))
     om = ob.OraclePhotonMap(o, scenes.oracle_camera(cam_args), photon_num=20000, times=2, background=(10, 10, 10), seed=6, aa=dict(oversample_times=os_))
     mg, mo = gm.edge_mask(), om.edge_mask()
-    assert mo.sum() >= 200 and (mo == 0).sum() >= 200 and (mg != mo).mean() <= 1e-3
+    assert mo.sum() >= 200 and (mo == 0).sum() >= 200
+    pl.allow("mask_mismatches", (mg != mo).sum(), mo.size, bar_count=MASK_FLIPS, cause="a Laplacian within rounding of its threshold")
     gh, oh = gm.hitpoints(), om.hitpoints()
     print("ppm aa: %d masked pixels of %d, hit points %d vs %d" % (int(mo.sum()), mo.size, len(gh), len(oh)))
     assert len(gh) == len(oh) and (gh[:, :2] == oh[:, :2]).all()                 # same (pixel, (ray << 12) | path) keys
     assert (np.bincount(oh[:, 0].astype(np.int64), minlength=mo.size)[mo == 1] > 1).mean() > 0.5      # masked pixels hold several rays' hit points
     assert np.abs(gh[:, 2:9] - oh[:, 2:9]).max() < 1e-6
     d0 = np.abs(gm.picture() - om.picture()).max(axis=1)
-    assert (d0 > 1).mean() <= 1e-3                                              # picture_ori: truncation of colours that agree to ~1e-13
+    pl.allow("eye pass: pixels off by more than one", (d0 > 1).sum(), d0.size, bar_count=0)      # picture_ori: truncation of colours that agree to ~1e-13
     for t in range(2):
         gm.run_pass(t); om.run_pass(t)
         gh, oh = gm.hitpoints(), om.hitpoints()
         dN = np.abs(gh[:, 10] - oh[:, 10])
         print("ppm aa pass %d: N total %.1f vs %.1f, hit points with different N %d" % (t, gh[:, 10].sum(), oh[:, 10].sum(), int((dN > 1e-9).sum())))
-        assert (dN > 1e-9).mean() < 1e-3
+        pl.allow("pass %d: hit points with different N" % t, (dN > 1e-9).sum(), len(dN), bar=1e-3, cause="photons on the rim of a gather disc")
     pg, po = gm.picture(), om.picture()
     d = np.abs(pg - po).max(axis=1)
     print("ppm aa: picture max |diff| %d, pixels differing %d of %d; masked pixels brighter than the eye pass: %d" % (
         d.max(), int((d > 0).sum()), d.size, int(((po.sum(axis=1) > 0) & (mo == 1)).sum())))
-    assert (d > 2).mean() <= 1e-3 and (d > 0).mean() < 1e-2
+    pl.allow("picture: pixels off by more than 2", (d > 2).sum(), d.size, bar_count=0)
+    pl.allow("picture: pixels differing", (d > 0).sum(), d.size, bar=1e-3, cause="round(sum / oversampleTimes) and Vec3b(tau) truncation of values within rounding of a boundary")
     info, oc = gm.info(), om.counters()
     assert abs(info["photon_hits"] - oc["photon_hits"]) <= 1e-4 * oc["photon_hits"]
     # the plain driver on the same scene has one ray per pixel: fewer hit points
@@ -221,8 +227,9 @@ def test_godray_antialiasing_parity(ctx):
     agree = mask == mask_ref
     err = _rel_err(rgb, rgb_ref)[agree]
     print("godray aa: %d masked pixels of %d, mask mismatches %d, max rel err %.3g" % (int(mask_ref.sum()), mask.size, int((~agree).sum()), err.max()))
-    assert mask_ref.sum() >= 100 and (mask_ref == 0).sum() >= 100 and (~agree).mean() <= 1e-3
-    assert err.max() < 1e-3
+    assert mask_ref.sum() >= 100 and (mask_ref == 0).sum() >= 100
+    pl.allow("mask_mismatches", (~agree).sum(), mask.size, bar_count=MASK_FLIPS, cause="a Laplacian within rounding of its threshold")
+    pl.value("max_rel_colour_err", err.max(), 1e-3)
     # unmasked pixels are the plain god-ray frame; the light shafts are in it (it differs from the shaft-less render)
     plain, _ = gg.render(rta.Camera(**cam_args), background=(20, 20, 30))
     keep = mask == 0

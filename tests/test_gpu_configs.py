@@ -2,50 +2,25 @@
 (SURVEY 8d): C3 = Layout3_Icosahedron depth of field with the 10x10 area light at 1920x1080; C4 = Layout2_WallAndPaper
 with WallLight.obj (11,578 objects) at 1920x1080 depth 2; C5 = Layout5_Wine with its three cups (uRange 0.7 / 0.5 / 0.8),
 5x5 area light, depth 8: eye-pass rows at 1920x1080, and a photon-mapping run of the same scene at reduced resolution and
-photon count (the oracle's photon tracing is too slow for 10 M photons).  Mismatch counts are printed."""
-import ctypes as C
-
-import numpy as np
+photon count (the oracle's photon tracing is too slow for 10 M photons).  The comparisons are tests/config_parity.py's (bench.py puts
+the same counts into its JSON line); every count goes through parity_log (profiles/r03_parity_counts.json)."""
 import pytest
 
+import config_parity as cp
+import parity_log as pl
 import scenes
-from parity_util import rel_err
 
 pytestmark = pytest.mark.gpu
-
-
-def _rows(rta, ctx, g, cam, rows, fn="whitted", **pk):
-    """product colours (and ids) of whole image rows through the ABI's pixel shard"""
-    out = {}
-    w = cam.width
-    for r in rows:
-        p = rta.Params(pixel_first=r * w, pixel_count=w, **pk)
-        rgb = np.zeros((w, 3)); ids = np.zeros(w, dtype=np.int32)
-        if fn == "whitted":
-            rta.check(rta.hip.rt_hip_render_whitted(g.device(ctx), cam.raw, p, rgb.ctypes.data, ids.ctypes.data))
-        else:
-            rta.check(rta.hip.rt_hip_render_focusing(g.device(ctx), cam.raw, p, rgb.ctypes.data))
-        out[r] = (rgb, ids)
-    return out
 
 
 def test_c3_depth_of_field_full_size_rows(ctx):
     import ray_tracing_amd as rta
     g, o = scenes.build_icosahedron(material="plastic", light="area10")
-    cam = rta.Camera(**scenes.C3_CAMERA)
-    assert (cam.width, cam.height) == (1920, 1080)
-    ocam = scenes.oracle_camera(scenes.C3_CAMERA)
-    spp = 3
-    rows = (200, 700, 1000)
-    got = _rows(rta, ctx, g, cam, rows, fn="focusing", background=(200, 200, 200), seed=7, spp=spp, lens_radius=0.1)
-    worst = 0.0
-    for r in rows:
-        ref = o.render_focusing(ocam, 0.1, spp, background=(200, 200, 200), seed=7, first=r * cam.width, count=cam.width)
-        e = rel_err(np.minimum(255.0, got[r][0]), ref)
-        worst = max(worst, e.max())
-        # a lens sample whose camera ray ties between two objects may differ: such pixels are counted, not hidden
-        assert (e.max(axis=1) > 1e-3).mean() <= 1e-3
-    print("C3 1920x1080, 10x10 light, %d spp, rows %s: max rel err %.3g" % (spp, rows, worst))
+    par, _ = cp.c3_rows(rta, ctx, g, o, rows=(200, 700, 1000), spp=3)
+    print("C3", par)
+    # a lens sample whose camera ray ties between two objects may differ: such pixels are counted, not hidden (observed: 0)
+    pl.allow("pixels_off_by_more_than_1e-3", par["pixels_off_by_more_than_1e-3"], par["pixels"], bar_count=1, cause="camera-ray ties of single lens samples")
+    pl.value("max_rel_colour_err_elsewhere", par["max_rel_colour_err_elsewhere"], 1e-3)
 
 
 def test_c4_wall_light_full_size_rows(ctx):
@@ -53,65 +28,34 @@ def test_c4_wall_light_full_size_rows(ctx):
     g, o = scenes.build_paper()
     assert g.num_objects == o.num_objects == 11578                 # plane + patch + 11,576 triangles
     assert g.tree_stats() == o.tree_stats()
-    cam = rta.Camera(**scenes.C4_CAMERA)
-    assert (cam.width, cam.height) == (1920, 1080)
-    ocam = scenes.oracle_camera(scenes.C4_CAMERA)
-    rows = (150, 400, 640, 900)
-    got = _rows(rta, ctx, g, cam, rows, background=(30, 30, 30))
-    n_bad = n_all = n_patch = n_mesh = 0
-    worst = 0.0
-    for r in rows:
-        ref_rgb, ref_ids = o.render_whitted(ocam, background=(30, 30, 30), first=r * cam.width, count=cam.width)
-        rgb, ids = got[r]
-        same = ids == ref_ids
-        n_bad += int((~same).sum()); n_all += len(ids); n_patch += int((ref_ids == 1).sum()); n_mesh += int((ref_ids >= 2).sum())
-        worst = max(worst, rel_err(rgb[same], ref_rgb[same]).max())
-    print("C4 1920x1080 on WallLight.obj, rows %s: %d / %d id mismatches, %d patch and %d mesh pixels, max rel err %.3g" % (rows, n_bad, n_all, n_patch, n_mesh, worst))
-    assert n_patch > 500 and n_mesh > 300
-    assert n_bad / n_all <= 1e-4 and worst < 1e-3
+    par, _ = cp.c4_rows(rta, ctx, g, o, rows=(150, 400, 640, 900))
+    print("C4", par)
+    assert par["patch_pixels"] > 500 and par["mesh_pixels"] > 300
+    pl.allow("id_mismatches", par["id_mismatches"], par["pixels"], bar=1e-4, cause="t-ties")
+    pl.value("max_rel_colour_err", par["max_rel_colour_err"], 1e-3)
 
 
 def test_c5_wine_layout_eye_rows_and_photon_pass(ctx):
     import ray_tracing_amd as rta
-    import oracle_bind as ob
     g, o = scenes.build_wine(cups="layout", light="area5")
     assert g.num_objects == o.num_objects == 24
-    cam = rta.Camera(**scenes.C5_CAMERA)
-    assert (cam.width, cam.height) == (1920, 1080)
-    ocam = scenes.oracle_camera(scenes.C5_CAMERA)
-    rows = (420, 650)
-    got = _rows(rta, ctx, g, cam, rows, background=(10, 10, 10), seed=2)
-    n_bad = n_all = n_off = 0
-    for r in rows:
-        ref_rgb, ref_ids = o.render_whitted(ocam, background=(10, 10, 10), seed=2, first=r * cam.width, count=cam.width)
-        rgb, ids = got[r]
-        same = ids == ref_ids
-        e = rel_err(rgb[same], ref_rgb[same]).max(axis=1)
-        n_bad += int((~same).sum()); n_all += len(ids); n_off += int((e > 1e-3).sum())
-        assert (ref_ids >= 3).sum() > 100                          # the row crosses the cups
-    # pixels whose ray tree meets two Newton roots 2 pi k apart (Object.h:864, 870 commented out) may take the other branch
-    print("C5 eye pass 1920x1080 depth 8, rows %s: %d / %d primary id mismatches, %d pixels off by > 1e-3" % (rows, n_bad, n_all, n_off))
-    assert n_bad / n_all <= 1e-4 and n_off / n_all <= 2e-3
+    par, _ = cp.c5_eye_rows(rta, ctx, g, o, rows=(420, 650))
+    print("C5 eye", par)
+    assert par["cup_pixels"] > 200                                 # the rows cross the cups
+    pl.allow("id_mismatches", par["id_mismatches"], par["pixels"], bar=1e-4, cause="t-ties")
+    # pixels whose ray tree meets a Newton iteration on its convergence threshold (|step|^2 ~ 1e-8) in one of the deeper rays may take the
+    # other branch: north_star's 1e-3 per pixel holds for all but these, which are counted
+    pl.allow("pixels_off_by_more_than_1e-3", par["pixels_off_by_more_than_1e-3"], par["pixels"], bar_count=3, cause="Newton iteration on its convergence threshold in a deep ray")
     # photon mapping on the same scene (three cups, 5x5 light): reduced frame and photon count, two passes
-    small = dict(scenes.C5_CAMERA, res=24)                         # 192 x 108
-    pm = rta.PhotonMap(ctx, g, rta.Camera(**small), photon_num=1500, times=2, background=(10, 10, 10), seed=4)
-    om = ob.OraclePhotonMap(o, scenes.oracle_camera(small), photon_num=1500, times=2, background=(10, 10, 10), seed=4)
-    for t in range(2):
-        pm.run_pass(t); om.run_pass(t)
-    hp, hr = pm.hitpoints(), om.hitpoints()
-    assert pm.info()["photons_per_pass"] == 1500 * 25
-    # depth 8 through three glass cups: a ray tree whose Newton iteration lands on the other of two roots 2 pi k apart
-    # (Object.h:864, 870 commented out) or whose weight sits on the 0.1 cut may branch differently; such hit points are
-    # counted, the rest must agree
-    kp = hp[:, 0].astype(np.int64) * 65536 + hp[:, 1].astype(np.int64)
-    kr = hr[:, 0].astype(np.int64) * 65536 + hr[:, 1].astype(np.int64)
-    common, ip, ir = np.intersect1d(kp, kr, return_indices=True)
-    only = len(kp) + len(kr) - 2 * len(common)
-    n_same = int((np.abs(hp[ip, 10] - hr[ir, 10]) <= 1e-9).sum())
-    pos = np.abs(hp[ip, 2:5] - hr[ir, 2:5]).max(axis=1)
-    dpic = np.abs(pm.picture() - om.picture()).max(axis=1)
-    print("C5 photon map 192x108 depth 8, 37,500 photons x 2 passes: hit points %d vs %d (%d not shared), N equal on %d of %d shared, "
-          "positions off by > 1e-6 on %d, picture pixels off by > 1: %d of %d" % (len(hp), len(hr), only, n_same, len(common), int((pos > 1e-6).sum()), int((dpic > 1).sum()), len(dpic)))
-    assert len(common) > 15000 and only / len(common) <= 2e-3
-    assert n_same / len(common) >= 1 - 2e-3 and (pos > 1e-6).mean() <= 2e-3
-    assert (dpic > 2).mean() <= 2e-3
+    ppm, _ = cp.c5_photon_map(rta, ctx, g, o, res=24, photon_num=1500, passes=2)
+    print("C5 photon map", ppm)
+    n = ppm["hit_points_shared"]
+    assert n > 15000
+    # depth 8 through three glass cups: a ray tree whose weight sits on the 0.1 cut or whose Newton iteration ends on its threshold may branch
+    # differently; such hit points are counted, the rest must agree
+    # (observed on the GPU box, profiles/r03_parity_counts.json: 4 hit points not shared, 11 positions, 1 picture pixel, 0 N of 21,651; bars = 2 x + 1)
+    pl.allow("hit_points_not_shared", ppm["hit_points_not_shared"], n, bar_count=9, cause="ray trees branching differently at depth 8")
+    pl.allow("shared_with_different_N", ppm["shared_with_different_N"], n, bar_count=3, cause="photons on the rim of a gather disc, |dist - R| ~ 1e-13")
+    pl.allow("shared_with_position_off", ppm["shared_with_position_off_by_more_than_1e-6"], n, bar_count=23, cause="ray trees branching differently at depth 8")
+    pl.allow("picture_pixels_off_by_more_than_2", ppm["picture_pixels_off_by_more_than_2"], ppm["picture_pixels"], bar_count=3, cause="the hit points above")
+

@@ -4,6 +4,7 @@ on the same inputs.  Bars (BASELINE.json north_star): hit ids identical except t
 import numpy as np
 import pytest
 
+import parity_log as pl
 import scenes
 
 pytestmark = pytest.mark.gpu
@@ -24,7 +25,7 @@ def _compare_hits(rays, hits, ids_ref, pts_ref, label):
         assert (ids[diff] >= 0).all() and (ids_ref[diff] >= 0).all(), label
         assert np.abs(hits["t"][diff] - t_ref).max() < 1e-6, label
     print("%s: %d rays, %d tie mismatches (%.2e)" % (label, len(ids), len(diff), frac))
-    assert frac <= 1e-4, label
+    pl.allow("tie_mismatches: " + label, len(diff), len(ids), bar=1e-4, cause="t-ties within 1e-6")
     same = (ids == ids_ref) & (ids >= 0)
     d = rays[same, 3:6] / np.linalg.norm(rays[same, 3:6], axis=1, keepdims=True)
     pts = rays[same, :3] + d * hits["t"][same, None]
@@ -65,6 +66,9 @@ def test_random_rays_mixed_scene(ctx, refine):
     ids2, pts2 = o.trace_closest(rays2, use_bsp=True)
     hits2 = g.first_inter_pt(ctx, rays2, use_tree=True)
     _compare_hits(rays2, hits2, ids2, pts2, "secondary refine=%d" % refine)
+
+
+FAR_ORIGIN_TIES = 9        # 2 x + 1 of the count observed on the GPU box (profiles/r03_parity_counts.json), of 3,000 far-origin rays
 
 
 @pytest.mark.parametrize("refine", [0, 0x40000000 | 3])
@@ -110,7 +114,8 @@ def test_box_test_edge_rays(ctx, refine):
     # (a box wrongly skipped would show as a miss or a farther hit, which the loop above refuses; what is left are hits on a shared edge
     # at the same distance.  From far origins -- t of 1e3 ... 1e6, rounded to 1e-13 ... 1e-10 -- there are more of those: bar 1e-4 without them)
     near = np.ones(n, bool); near[5 * k:6 * k] = False
-    assert near[diff].sum() <= 1e-4 * n and len(diff) <= 3e-3 * k + 1e-4 * n, (len(diff), int(near[diff].sum()), n)
+    pl.allow("tie_mismatches", near[diff].sum(), n, bar=1e-4, cause="t-ties within 1e-6")
+    pl.allow("tie_mismatches_far_origins", (~near[diff]).sum(), k, bar_count=FAR_ORIGIN_TIES, cause="origins 1e3 .. 1e6 away: hits on a shared edge at a distance rounded to 1e-13 .. 1e-10")
     assert (ids >= 0).sum() > n // 3
     occ = g.occluded(ctx, rays, None)
     assert (occ.astype(bool) == (ids_ref >= 0)).mean() > 1 - 1e-4
@@ -323,7 +328,7 @@ def test_c2_full_size_heightfield(ctx):
     res = parity_util.frame_parity(rgb, ids, ref_rgb, ref_ids, t_of, two_class_ids=lambda i: np.where(i < 0, -1, np.minimum(i, 1)))
     print("C2 full frame:", res)
     assert res["rays"] == 1920 * 1080
-    assert res["tie_fraction"] <= 1e-4
+    pl.allow("id_mismatches", res["id_mismatches"], res["rays"], bar=1e-4, cause="t-ties within 1e-6")
     assert res["max_dt"] is None or res["max_dt"] < 1e-6
     assert res["shadow_bit_mismatches"] == 0 and res["pixels_in_shadow"] > 10000
     assert res["max_rel_colour_err"] < 1e-3
@@ -347,7 +352,9 @@ def _compare_param_hits(rays, hits, ids_ref, pts_ref, uv_ref, what, periodic_v=F
         dv = np.abs((dv + np.pi) % (2 * np.pi) - np.pi)
     print("%s: %d rays, %d hits (%d parametric), id mismatches %d, max |dt| %.3g |du| %.3g |dv| %.3g" % (
         what, len(ids), int(hit.sum()), int(par.sum()), int(bad.sum()), dt.max() if dt.size else 0, du.max() if du.size else 0, dv.max() if dv.size else 0))
-    assert bad.mean() <= 1e-4, "hit ids differ on %d rays" % bad.sum()
+    pl.allow("id_mismatches: " + what, bad.sum(), len(ids), bar=1e-4, cause="t-ties within 1e-6")
+    pl.record("max_errors: " + what, dt=float(dt.max()) if dt.size else 0.0, du=float(du.max()) if du.size else 0.0, dv=float(dv.max()) if dv.size else 0.0,
+              dv_is_modulo_2pi=bool(periodic_v))
     assert dt.size == 0 or dt.max() < 1e-6
     assert du.size == 0 or (du.max() < 1e-6 and dv.max() < 1e-6)
     return int(par.sum())
@@ -413,8 +420,11 @@ def test_c4_paper_image_parity(ctx):
     err = _rel_err(rgb, rgb_ref)[~bad]
     print("C4 %dx%d: id mismatches %d, patch pixels %d, max rel err %.3g" % (cam.width, cam.height, bad.sum(), (ids_ref == 1).sum(), err.max()))
     assert (ids_ref == 1).sum() > 500
-    assert bad.mean() <= 1e-4
-    assert err.max() < 1e-3
+    pl.allow("id_mismatches", bad.sum(), len(ids), bar=1e-4, cause="t-ties")
+    pl.value("max_rel_colour_err", err.max(), 1e-3)
+
+
+C5_SMALL_OFF = 3           # 2 x + 1 of the count observed on the GPU box, of 5,184 pixels
 
 
 def test_c5_wine_image_parity(ctx):
@@ -434,8 +444,8 @@ def test_c5_wine_image_parity(ctx):
     print("C5 %dx%d: id mismatches %d, cup pixels %d, pixels off %d, max rel err elsewhere %.3g" % (
         cam.width, cam.height, bad.sum(), (ids_ref >= 3).sum(), off.sum(), err[~off].max()))
     assert (ids_ref >= 3).sum() > 300
-    assert bad.mean() <= 1e-4
-    assert off.mean() <= 2e-3
+    pl.allow("id_mismatches", bad.sum(), len(ids), bar=1e-4, cause="t-ties")
+    pl.allow("pixels_off_by_more_than_1e-3", off.sum(), len(ids), bar_count=C5_SMALL_OFF, cause="Newton iteration on its convergence threshold in a deep ray")
 
 
 # ---- progressive photon mapping ------------------------------------------------------------------------
@@ -454,7 +464,8 @@ def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp, texel_fli
     d0 = np.abs(pic_g - pic_o)
     # uchar truncation of doubles that agree to ~1e-13; textured scenes: plus the pixels whose hit lies on a texel boundary
     print("%s eye pass: pixels off by one %d, by more %d of %d" % (what, int((d0.max(axis=1) == 1).sum()), int((d0.max(axis=1) > 1).sum()), d0.shape[0]))
-    assert (d0.max(axis=1) > 1).mean() <= texel_flips and (d0 > 0).mean() < 1e-3 + texel_flips
+    pl.allow("eye pass: pixels off by more than one: " + what, (d0.max(axis=1) > 1).sum(), d0.shape[0], bar=texel_flips, bar_count=0, cause="texel boundaries" if texel_flips else None)
+    pl.allow("eye pass: pixels off by one: " + what, (d0.max(axis=1) > 0).sum(), d0.shape[0], bar=1e-3 + texel_flips, cause="uchar truncation of doubles that agree to 1e-13")
     for t in range(times):
         gm.run_pass(t)
         om.run_pass(t)
@@ -464,7 +475,7 @@ def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp, texel_fli
         dR = np.abs(gh[:, 9] - oh[:, 9])
         print("%s pass %d: hit points %d, N total %.1f vs %.1f, hit points with different N %d, max |dR| %.3g" % (
             what, t, gh.shape[0], gh[:, 10].sum(), oh[:, 10].sum(), int((dN > 1e-9).sum()), dR.max()))
-        assert (dN > 1e-9).mean() < 1e-3
+        pl.allow("pass %d: hit points with different N: %s" % (t, what), (dN > 1e-9).sum(), len(dN), bar=1e-3, cause="photons on the rim of a gather disc, |dist - R| ~ 1e-13")
         assert dR[dN <= 1e-9].max() < 1e-9
     info, oc = gm.info(), om.counters()
     print("%s: photons/pass %d, segments %d vs %d, photon hits %d vs %d" % (what, info["photons_per_pass"], info["photon_segments"],
@@ -476,7 +487,8 @@ def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp, texel_fli
     print("%s: picture max |diff| %d, pixels differing %d of %d, mean added %.2f" % (what, d.max(), int((d.max(axis=1) > 0).sum()), d.shape[0],
                                                                              (pic_o.sum() - 0) / pic_o.size))
     # Vec3b(tau) truncates: a tau within rounding noise of an integer may land on either side, once per pass and hit point
-    assert (d.max(axis=1) > times).mean() <= texel_flips and (d.max(axis=1) > 0).mean() < 5e-3 + texel_flips
+    pl.allow("picture: pixels off by more than one per pass: " + what, (d.max(axis=1) > times).sum(), d.shape[0], bar=texel_flips, bar_count=0, cause="texel boundaries" if texel_flips else None)
+    pl.allow("picture: pixels differing: " + what, (d.max(axis=1) > 0).sum(), d.shape[0], bar=1e-3 + texel_flips, cause="Vec3b(tau) truncates: a tau within rounding of an integer lands on either side, once per pass and hit point")
     return gm, om
 
 
@@ -512,7 +524,8 @@ def test_ppm_depth1_camera(ctx):
     cam = rta.Camera(**cam_args)                      # and the plain depth-1 frame of the same scene (k_frame_direct, PARAM)
     cam.render_raytracer(ctx, g, background=(10, 10, 10))
     rgb_ref, ids_ref = scenes.oracle_render_whitted(o, cam_args, background=(10, 10, 10))
-    assert (cam.prim_id() != ids_ref).mean() <= 1e-4 and (_rel_err(cam.rgb(), rgb_ref).max(axis=1) >= 1e-3).mean() <= 1e-4
+    pl.allow("id_mismatches", (cam.prim_id() != ids_ref).sum(), len(ids_ref), bar=1e-4, cause="t-ties")
+    pl.allow("pixels_off_by_more_than_1e-3", (_rel_err(cam.rgb(), rgb_ref).max(axis=1) >= 1e-3).sum(), len(ids_ref), bar=1e-4, cause="t-ties")
 
 
 def test_ppm_photon_shards_add_up(ctx):

@@ -5,6 +5,7 @@ neighbouring texel, so a fraction <= 5e-4 of the pixels (reported) may differ; a
 import numpy as np
 import pytest
 
+import parity_log as pl
 import scenes
 from test_gpu_parity import _ppm_compare
 
@@ -15,11 +16,14 @@ def _rel_err(a, b):
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
 
+TEXEL_PIXELS = 11          # 2 x + 1 of the count observed on the GPU box (profiles/r03_parity_counts.json: 5 of 110,592)
+
+
 def _check_image(rgb, rgb_ref, what):
     err = _rel_err(rgb, rgb_ref).max(axis=1)
     bad = err >= 1e-3
     print("%s: max rel err on agreeing pixels %.3g, texel-boundary pixels %d of %d" % (what, err[~bad].max(), int(bad.sum()), bad.size))
-    assert bad.mean() <= 5e-4
+    pl.allow("texel_boundary_pixels: " + what, bad.sum(), bad.size, bar_count=TEXEL_PIXELS, cause="a hit within an ulp of a texel boundary (atan2 / asin of the device library vs glibc) reads the neighbouring texel")
 
 
 @pytest.mark.parametrize("bsp,light,depth", [(True, "point_area", 3), (False, "area", 2)])
@@ -40,6 +44,9 @@ def test_textured_scene_image_parity(ctx, bsp, light, depth):
     assert (np.abs(rgb_ref - rgb_ref.mean(axis=0)).max(axis=1) > 1).mean() > 0.5
 
 
+TEX_AA_MASK, TEX_AA_PIXELS = 3, 9           # 2 x + 1 of the counts observed on the GPU box (profiles/r03_parity_counts.json: 0 and 4 of 27,648)
+
+
 def test_textured_scene_antialiasing(ctx):
     """the colour maps of the anti-aliasing driver see the texture edges (Camera.h:147-149)"""
     import ray_tracing_amd as rta
@@ -52,10 +59,11 @@ def test_textured_scene_antialiasing(ctx):
     mask = cam.edge_mask()
     agree = mask == mask_ref
     print("textured aa: %d masked pixels of %d, mask mismatches %d" % (int(mask_ref.sum()), mask.size, int((~agree).sum())))
-    assert (~agree).mean() <= 2e-3 and mask_ref.mean() > 0.2
+    assert mask_ref.mean() > 0.2
+    pl.allow("mask_mismatches", (~agree).sum(), mask.size, bar_count=TEX_AA_MASK, cause="texel-boundary pixels change the colour maps' Laplacian")
     err = _rel_err(cam.rgb(), rgb_ref).max(axis=1)[agree]
     # a jittered sample on a texel boundary moves a masked pixel's mean by 1 / oversample_times of a texel difference
-    assert (err >= 1e-3).mean() <= 5e-3
+    pl.allow("pixels_off_by_more_than_1e-3", (err >= 1e-3).sum(), err.size, bar_count=TEX_AA_PIXELS, cause="jittered samples on texel boundaries")
 
 
 def test_textured_photon_map(ctx):
@@ -63,7 +71,7 @@ def test_textured_photon_map(ctx):
     the bump-mapped ones (PhotonMapper.h:178)"""
     g, o = scenes.build_textured(bsp=True, light="area")
     cam_args = dict(scenes.TEX_CAMERA, res=12, depth=3)
-    _ppm_compare(ctx, g, o, cam_args, 3000, 2, "textured ppm", 3000, texel_flips=1e-3)
+    _ppm_compare(ctx, g, o, cam_args, 3000, 2, "textured ppm", 3000, texel_flips=5 / 9890.0)      # observed: 2 of 9,890 pixels on texel boundaries
 
 
 def test_texture_argument_errors(ctx):
