@@ -138,11 +138,20 @@ static uint32_t own_leaf_default(uint32_t n_objects) { return n_objects <= kSmal
 
 struct Box { double mn[3], mx[3]; };
 
+#ifndef RT_TEST_NO_HULL_BOXES
+#define RT_TEST_NO_HULL_BOXES 0   /* 1: a build WITHOUT the hull boxes below, to see tests/test_gpu_parity.py::test_rotational_overshoot_in_tree fail on it */
+#endif
 struct Builder {
   const rt_hip_scene_desc *d;
   uint32_t leaf_refine;
   std::vector<Box> aabb;            // per object (finite ones)
   std::vector<uint8_t> finite;
+  // Surfaces of revolution whose surface leaves their m_AABB: CRotationalObject::InitializeAABB takes z from the profile's two END points only
+  // (Object.h:954-957), and the reference uses that box as a ray filter and for the tree's lists, not as a bound of the surface -- a profile whose
+  // inner control points overshoot in height is hit OUTSIDE it.  The walk prunes by leaf boxes, so every leaf that lists such an object has its box
+  // grown (unclipped) to the object's control-hull box (rt_param.hpp: param_prune_box): the hit lies in the leaf's box whatever the tree.
+  std::vector<uint8_t> loose;       // per object: 1 = hull[] holds a box that reaches beyond aabb[]
+  std::vector<Box> hull;
   std::vector<DPair> pairs;
   std::vector<unsigned char> stream;   // leaf headers + records
   std::vector<TriExact> tri_exact;
@@ -164,7 +173,7 @@ struct Builder {
   // CSphere ctor (Object.h:234); planes and circles keep the infinite default (Object.h:34)
   void object_boxes()
   {
-    aabb.resize(d->n_objects); finite.assign(d->n_objects, 0);
+    aabb.resize(d->n_objects); finite.assign(d->n_objects, 0); loose.assign(d->n_objects, 0); hull.resize(d->n_objects);
     for (uint32_t i = 0; i < d->n_objects; i++) {
       uint32_t k = d->obj_index[i];
       Box b;
@@ -188,8 +197,18 @@ struct Builder {
         }
         finite[i] = 1;
       } else if (d->obj_type[i] == RT_HIP_ROTATIONAL) {      // CRotationalObject::InitializeAABB, Object.h:954-970
-        rot_box(d->rotationals[k], b.mn, b.mx);
+        const rt_hip_rotational &z = d->rotationals[k];
+        rot_box(z, b.mn, b.mx);
         finite[i] = 1;
+        DRotational o; std::memset(&o, 0, sizeof o);
+        std::memcpy(o.prof, z.profile, sizeof o.prof); std::memcpy(o.center, z.center, 24);
+        o.u_range = z.u_range; o.n_prof = z.n_profile; o.u_sample_num = z.u_sample_num;
+        rot_box(z, o.bmin, o.bmax);
+        param_prune_box(o);                                   // pmin / pmax: where an accepted hit can lie
+        for (int a = 0; a < 3; a++) {
+          hull[i].mn[a] = std::min(b.mn[a], o.pmin[a]); hull[i].mx[a] = std::max(b.mx[a], o.pmax[a]);
+          if (o.pmin[a] < b.mn[a] || o.pmax[a] > b.mx[a]) loose[i] = 1;
+        }
       } else {
         for (int a = 0; a < 3; a++) { b.mn[a] = kInfty; b.mx[a] = kInfty; }
       }
@@ -254,6 +273,10 @@ struct Builder {
       out.box.mx[a] = std::min(cell.mx[a], u.mx[a]) + kBoxPad;
       H.bmin[a] = f32_down(out.box.mn[a]); H.bmax[a] = f32_up(out.box.mx[a]);
     }
+    for (uint32_t id : objs)
+      if (loose[id] && !RT_TEST_NO_HULL_BOXES)
+        for (int a = 0; a < 3; a++) { out.box.mn[a] = std::min(out.box.mn[a], hull[id].mn[a] - kBoxPad); out.box.mx[a] = std::max(out.box.mx[a], hull[id].mx[a] + kBoxPad); }
+    for (int a = 0; a < 3; a++) { H.bmin[a] = f32_down(out.box.mn[a]); H.bmax[a] = f32_up(out.box.mx[a]); }
     H.count = (int32_t)objs.size();
     size_t off = stream.size();
     if (off / 64 > 0x7FFFFFFFu) { err = "leaf stream too large"; out.empty = true; return out; }

@@ -407,6 +407,46 @@ def test_rotational_object_rays(ctx, record):
     _compare_param_hits(rays2, hits2, ids2, pts2, uv2, "rotational secondary record=%s" % record, periodic_v=True)
 
 
+@pytest.mark.parametrize("refine", [0xFFFFFFFF, 0, 8])       # the reference's tree, the library's own hierarchy, the refined reference tree
+def test_rotational_overshoot_in_tree(ctx, refine):
+    """A surface of revolution whose inner profile points overshoot BOTH end heights, inside a BSP scene.  m_AABB takes z from the two end
+    points only (Object.h:954-957): the reference uses it as a ray filter and for the tree's lists, and hits the surface outside it.  A walk that
+    prunes by leaf boxes built from m_AABB loses those hits whenever another object lies between the hit and the box (Scene.h:349-368 tests the
+    object in every listing leaf the ray reaches, whatever the distance): the leaf boxes are grown to the control hull instead."""
+    P = scenes._Pair(0.5)
+    pl_, gl = P.mat("plastic"), P.mat("glass")
+    P.call("add_plane", (0, 0, -1), (0, 0, 1), mat=pl_, colour=(200, 200, 200))
+    # a vase from z = 0 up to ~3.1 and back down to z = 1: everything above z = 1 lies outside m_AABB = [.., .., 0] .. [.., .., 1]
+    P.call("add_rotational", [(0.8, 0.0), (1.4, 4.0), (1.4, 4.0), (0.6, 1.0)], (0.0, 0.0, 0.0), 20, 1.0, mat=gl, colour=(155, 155, 155))
+    # a lid of small triangles INSIDE the vase at z = 1.5 (between the bulge and the box for rays from above) and a floor grid: > 100 objects, so the tree splits
+    tris = []
+    n = 9
+    for (z, half) in ((1.5, 0.9), (-0.5, 3.0)):
+        xs = np.linspace(-half, half, n + 1)
+        for i in range(n):
+            for j in range(n):
+                a, b, c, d = (xs[i], xs[j], z), (xs[i + 1], xs[j], z), (xs[i + 1], xs[j + 1], z), (xs[i], xs[j + 1], z)
+                tris += [(a, b, c), (a, c, d)]
+    P.call("add_triangles", np.array(tris, dtype=np.float64), mat=pl_, colour=(90, 160, 60))
+    P.call("construct_bsp", 0, 0)
+    P.g.set_leaf_refine(refine)
+    g, o = P.g, P.o
+    rng = np.random.default_rng(17)
+    m = 8000
+    dirs = rng.normal(size=(m, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True); dirs[:, 2] = np.abs(dirs[:, 2]) * 0.8 + 0.2
+    org = np.array([0.0, 0.0, 1.5]) + 7.0 * dirs / np.linalg.norm(dirs, axis=1, keepdims=True)
+    tgt = rng.uniform(-1, 1, (m, 3)) * np.array([1.0, 1.0, 1.6]) + np.array([0.0, 0.0, 1.4])
+    rays = np.concatenate([org, tgt - org], axis=1)
+    ids_ref, pts_ref, uv_ref = o.trace_closest(rays, use_bsp=True, want_uv=True)
+    hits = g.first_inter_pt(ctx, rays, use_tree=True)
+    outside = (ids_ref == 1) & (pts_ref[:, 2] > 1.05)
+    print("overshoot refine=%#x: %d vase hits, %d of them outside m_AABB" % (refine, int((ids_ref == 1).sum()), int(outside.sum())))
+    assert outside.sum() > 1500
+    _compare_param_hits(rays, hits, ids_ref, pts_ref, uv_ref, "overshooting profile refine=%#x" % refine, periodic_v=True)
+    occ = g.occluded(ctx, rays, None)
+    assert (occ.astype(bool) == (ids_ref >= 0)).all()
+
+
 def test_c4_paper_image_parity(ctx):
     """C4 at reduced resolution: plane + Bezier patch + mesh in the BSP tree, parallel light, depth 2"""
     import ray_tracing_amd as rta
