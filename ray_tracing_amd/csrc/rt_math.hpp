@@ -46,6 +46,60 @@ RT_HD V3 unitize(V3 a)                                                          
 RT_HD double dmin(double a, double b) { return (b < a) ? b : a; }   // std::min
 RT_HD double dmax(double a, double b) { return (a < b) ? b : a; }   // std::max
 
+// ---- sine, cosine and arc cosine by the same operations on every host and device -------------------------------------------------------
+// The angle of a surface of revolution is unbounded (Object.h:864, 870 are commented out): two Newton seeds can reach the same point 2 pi k
+// apart, and which root is "nearer" is decided in the last bits of t'.  With the C library's sin / cos / acos (glibc on the host, the device
+// library on the GPU; both accurate, neither the other's bit pattern) the checker and the kernels could take different roots.  These use
+// + - x / floor sqrt only (IEEE operations, -ffp-contract=off), so every build rounds alike: Cody-Waite reduction by a three-part pi/2
+// (exact products for |x| < ~1e6; beyond that the result is still the same everywhere, only less accurate) and the polynomial kernels
+// of Sun's fdlibm (k_sin.c, k_cos.c, e_acos.c without the split of sqrt's result); errors <= 2 ulp against glibc on [-200, 200] / [-1, 1].
+// oracle/rt_oracle.c restates them operation for operation.
+RT_HD void rt_sincos(double x, double *s_out, double *c_out)
+{
+  const double n = floor(x * 6.36619772367581382433e-01 + 0.5);                  // nearest multiple of pi/2
+  double r = ((x - n * 1.57079632673412561417e+00) - n * 6.07710050630396597660e-11) - n * 2.02226624871116645580e-21;
+  r = r - n * 8.47842766036889956997e-32;
+  const double z = r * r;
+  const double s = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                   z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+  const double c = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 +
+                   z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double q = n - 4.0 * floor(n * 0.25);                                    // n mod 4 in {0, 1, 2, 3}
+  if (q == 0.0) { *s_out = s; *c_out = c; }
+  else if (q == 1.0) { *s_out = c; *c_out = -s; }
+  else if (q == 2.0) { *s_out = -s; *c_out = -c; }
+  else { *s_out = -c; *c_out = s; }
+}
+RT_HD double rt_sin(double x) { double s, c; rt_sincos(x, &s, &c); return s; }
+RT_HD double rt_cos(double x) { double s, c; rt_sincos(x, &s, &c); return c; }
+RT_HD double rt_acos_ratio(double z)
+{
+  const double p = z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 + z * (2.01212532134862925881e-01 + z * (-4.00555345006794114027e-02 +
+                   z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+  const double q = 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 + z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+  return p / q;
+}
+RT_HD double rt_acos(double x)
+{
+  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pi = 3.14159265358979311600e+00;
+  const double ax = fabs(x);
+  if (!(ax < 1.0)) {
+    if (x == 1.0) return 0.0;
+    if (x == -1.0) return pi + 2.0 * pio2_lo;
+    return (x - x) / (x - x);                                                     // NaN, like acos
+  }
+  if (ax < 0.5) {
+    if (ax < 6.9388939039072284e-18) return pio2_hi + pio2_lo;
+    return pio2_hi - (x - (pio2_lo - x * rt_acos_ratio(x * x)));
+  }
+  if (x < 0) {
+    const double z = (1.0 + x) * 0.5, s = sqrt(z), w = rt_acos_ratio(z) * s - pio2_lo;
+    return pi - 2.0 * (s + w);
+  }
+  const double z = (1.0 - x) * 0.5, s = sqrt(z), w = rt_acos_ratio(z) * s;
+  return 2.0 * (s + w);
+}
+
 // ---- CColour (Colour.h:26-63): every operation clamps to <= 255 -----------------------------
 struct Col { double r, g, b; };
 RT_HD Col mkc(double r, double g, double b) { Col c; c.r = r; c.g = g; c.b = b; return c; }

@@ -203,16 +203,17 @@ RT_HD P2 curve_norm(const DRotational &R, double t)                            /
   return r;
 }
 // ---- CRotationalSurface (Bezier.h:65-87) ----
-RT_HD V3 rot_point(const DRotational &R, double t, double th) { P2 p = curve_pt(R, t, 0, R.n_prof - 1); return mk(p.u * cos(th), p.u * sin(th), p.v); }
-RT_HD V3 rot_norm(const DRotational &R, double t, double th) { P2 r = curve_norm(R, t); return unitize(mk(r.u * cos(th), r.u * sin(th), r.v)); }
-RT_HD V3 rot_ds_dt(const DRotational &R, double t, double th) { P2 dd = curve_tan(R, t); return mk(cos(th) * dd.u, sin(th) * dd.u, dd.v); }
-RT_HD V3 rot_ds_dth(const DRotational &R, double t, double th) { P2 p = curve_pt(R, t, 0, R.n_prof - 1); return mk(-(p.u) * sin(th), p.u * cos(th), 0); }
+// (sin / cos / acos of this file are rt_math.hpp's: the same bits on the host, on the device and in the oracle)
+RT_HD V3 rot_point(const DRotational &R, double t, double th) { P2 p = curve_pt(R, t, 0, R.n_prof - 1); double s, c; rt_sincos(th, &s, &c); return mk(p.u * c, p.u * s, p.v); }
+RT_HD V3 rot_norm(const DRotational &R, double t, double th) { P2 r = curve_norm(R, t); double s, c; rt_sincos(th, &s, &c); return unitize(mk(r.u * c, r.u * s, r.v)); }
+RT_HD V3 rot_ds_dt(const DRotational &R, double t, double th) { P2 dd = curve_tan(R, t); double s, c; rt_sincos(th, &s, &c); return mk(c * dd.u, s * dd.u, dd.v); }
+RT_HD V3 rot_ds_dth(const DRotational &R, double t, double th) { P2 p = curve_pt(R, t, 0, R.n_prof - 1); double s, c; rt_sincos(th, &s, &c); return mk(-(p.u) * s, p.u * c, 0); }
 // S, dS/dt, dS/dtheta at once (what one Newton step needs): one curve pass, one sine, one cosine
 RT_HD void rot_eval(const DRotational &R, double t, double th, V3 &S, V3 &dSt, V3 &dSth)
 {
   P2 p, dd; curve_eval(R, t, p, dd);
   double s, c;
-  sincos(th, &s, &c);              // one argument reduction for both (the device library's sin and cos run the same reduction and kernels)
+  rt_sincos(th, &s, &c);           // one argument reduction for both
   S = mk(p.u * c, p.u * s, p.v);
   dSt = mk(c * dd.u, s * dd.u, dd.v);
   dSth = mk(-(p.u) * s, p.u * c, 0);
@@ -367,7 +368,7 @@ RT_HD bool rot_seed(const DRotational &R, double u, V3 o, V3 d, double &t_out, d
   }
   // the seed must not compare equal to inftyPt2D (Object.h:848): only possible for |t|, |v| ~ 1e8
   double cos_theta = (p - p0).x / len(p - p0);
-  double theta = acos(cos_theta);
+  double theta = rt_acos(cos_theta);
   double v = (p.y > p0.y || (p.y == p0.y && p.x > p0.x)) ? theta : 2 * kPiRef - theta;
   if (fabs(t - kInfty) < kEps && fabs(v - kInfty) < kEps) return false;
   t_out = t; v_out = v;

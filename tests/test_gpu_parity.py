@@ -335,8 +335,10 @@ def test_c2_full_size_heightfield(ctx):
 
 
 # ---- Bezier patch / surface of revolution ----------------------------------------------------
-def _compare_param_hits(rays, hits, ids_ref, pts_ref, uv_ref, what, periodic_v=False):
-    """ids identical except where the two candidates are closer than 1e-6; t, u, v within 1e-6"""
+def _compare_param_hits(rays, hits, ids_ref, pts_ref, uv_ref, what):
+    """ids identical except where the two candidates are closer than 1e-6; t, u, v within 1e-6.  (The angle v of a surface of revolution is
+    unbounded, Object.h:864, 870 are commented out, and two Newton seeds can reach the same point 2 pi k apart: the kernels and the oracle take the
+    same one because both use rt_math.hpp's sin / cos / acos -- observed |dv| = 0, profiles/r03_parity_counts.json.)"""
     o = rays[:, :3]
     t_ref = np.linalg.norm(pts_ref - o, axis=1)
     ids = hits["prim_id"]
@@ -346,15 +348,10 @@ def _compare_param_hits(rays, hits, ids_ref, pts_ref, uv_ref, what, periodic_v=F
     par = hit & (uv_ref[:, 0] < 1e7)
     du = np.abs(hits["u"][par] - uv_ref[par, 0])
     dv = np.abs(hits["v"][par] - uv_ref[par, 1])
-    if periodic_v:
-        # theta of a surface of revolution is unbounded (Object.h:864, 870 are commented out): two Newton seeds reach the
-        # same point with angles 2 pi k apart, and which one is "nearer" is decided in the last bits of t'
-        dv = np.abs((dv + np.pi) % (2 * np.pi) - np.pi)
     print("%s: %d rays, %d hits (%d parametric), id mismatches %d, max |dt| %.3g |du| %.3g |dv| %.3g" % (
         what, len(ids), int(hit.sum()), int(par.sum()), int(bad.sum()), dt.max() if dt.size else 0, du.max() if du.size else 0, dv.max() if dv.size else 0))
     pl.allow("id_mismatches: " + what, bad.sum(), len(ids), bar=1e-4, cause="t-ties within 1e-6")
-    pl.record("max_errors: " + what, dt=float(dt.max()) if dt.size else 0.0, du=float(du.max()) if du.size else 0.0, dv=float(dv.max()) if dv.size else 0.0,
-              dv_is_modulo_2pi=bool(periodic_v))
+    pl.record("max_errors: " + what, dt=float(dt.max()) if dt.size else 0.0, du=float(du.max()) if du.size else 0.0, dv=float(dv.max()) if dv.size else 0.0)
     assert dt.size == 0 or dt.max() < 1e-6
     assert du.size == 0 or (du.max() < 1e-6 and dv.max() < 1e-6)
     return int(par.sum())
@@ -396,7 +393,7 @@ def test_rotational_object_rays(ctx, record):
     rays[:800, 3:] = np.array([1.0, 0, 0]) + rng.uniform(-0.05, 0.05, (800, 3))
     ids_ref, pts_ref, uv_ref = o.trace_closest(rays, use_bsp=False, record=record, want_uv=True)
     hits = g.first_inter_pt(ctx, rays, use_tree=False, record=record)
-    npar = _compare_param_hits(rays, hits, ids_ref, pts_ref, uv_ref, "rotational record=%s" % record, periodic_v=True)
+    npar = _compare_param_hits(rays, hits, ids_ref, pts_ref, uv_ref, "rotational record=%s" % record)
     assert npar > 1000
     # rays that start on the surfaces (refraction / reflection continue from there)
     ok = (ids_ref >= 3)
@@ -404,7 +401,7 @@ def test_rotational_object_rays(ctx, record):
     rays2 = np.concatenate([pts_ref[ok], d2], axis=1)
     ids2, pts2, uv2 = o.trace_closest(rays2, use_bsp=False, record=record, want_uv=True)
     hits2 = g.first_inter_pt(ctx, rays2, use_tree=False, record=record)
-    _compare_param_hits(rays2, hits2, ids2, pts2, uv2, "rotational secondary record=%s" % record, periodic_v=True)
+    _compare_param_hits(rays2, hits2, ids2, pts2, uv2, "rotational secondary record=%s" % record)
 
 
 @pytest.mark.parametrize("refine", [0xFFFFFFFF, 0, 8])       # the reference's tree, the library's own hierarchy, the refined reference tree
@@ -442,7 +439,7 @@ def test_rotational_overshoot_in_tree(ctx, refine):
     outside = (ids_ref == 1) & (pts_ref[:, 2] > 1.05)
     print("overshoot refine=%#x: %d vase hits, %d of them outside m_AABB" % (refine, int((ids_ref == 1).sum()), int(outside.sum())))
     assert outside.sum() > 1500
-    _compare_param_hits(rays, hits, ids_ref, pts_ref, uv_ref, "overshooting profile refine=%#x" % refine, periodic_v=True)
+    _compare_param_hits(rays, hits, ids_ref, pts_ref, uv_ref, "overshooting profile refine=%#x" % refine)
     occ = g.occluded(ctx, rays, None)
     assert (occ.astype(bool) == (ids_ref >= 0)).all()
 
@@ -489,7 +486,7 @@ def test_c5_wine_image_parity(ctx):
 
 
 # ---- progressive photon mapping ------------------------------------------------------------------------
-def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp, texel_flips=0.0):
+def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp, texel_flips=0.0, picture_flips=0):
     import oracle_bind as ob
     import ray_tracing_amd as rta
     cam = rta.Camera(**cam_args)
@@ -528,7 +525,7 @@ def _ppm_compare(ctx, g, o, cam_args, photon_num, times, what, min_hp, texel_fli
                                                                              (pic_o.sum() - 0) / pic_o.size))
     # Vec3b(tau) truncates: a tau within rounding noise of an integer may land on either side, once per pass and hit point
     pl.allow("picture: pixels off by more than one per pass: " + what, (d.max(axis=1) > times).sum(), d.shape[0], bar=texel_flips, bar_count=0, cause="texel boundaries" if texel_flips else None)
-    pl.allow("picture: pixels differing: " + what, (d.max(axis=1) > 0).sum(), d.shape[0], bar=1e-3 + texel_flips, cause="Vec3b(tau) truncates: a tau within rounding of an integer lands on either side, once per pass and hit point")
+    pl.allow("picture: pixels differing: " + what, (d.max(axis=1) > 0).sum(), d.shape[0], bar=1e-3, bar_count=picture_flips, cause="Vec3b(tau) truncates: a tau within rounding of an integer lands on either side, once per pass and hit point")
     return gm, om
 
 

@@ -71,7 +71,8 @@ def test_textured_photon_map(ctx):
     the bump-mapped ones (PhotonMapper.h:178)"""
     g, o = scenes.build_textured(bsp=True, light="area")
     cam_args = dict(scenes.TEX_CAMERA, res=12, depth=3)
-    _ppm_compare(ctx, g, o, cam_args, 3000, 2, "textured ppm", 3000, texel_flips=5 / 9890.0)      # observed: 2 of 9,890 pixels on texel boundaries
+    _ppm_compare(ctx, g, o, cam_args, 3000, 2, "textured ppm", 3000, texel_flips=5 / 9890.0, picture_flips=49)
+    # (observed on the GPU box: 2 of 9,890 eye-pass pixels on texel boundaries; 24 picture pixels whose photons picked up a neighbouring texel)
 
 
 def test_texture_argument_errors(ctx):
