@@ -2,6 +2,11 @@
 // that a layout ports line by line and to exercise the C++ side end to end (tests/test_gpu_examples.py runs it).
 //
 //   layouts focusing <Icosahedron_Triangle.obj> <out.ppm> [resolution] [spp]     Layout3_Focusing, Layout.h:134-160
+//   layouts raytracer <Icosahedron_Triangle.obj> <out.ppm> [resolution] [depth]  the same scene (metal mesh) through Render_RayTracer
+//
+//   focusing / raytracer / wine-plain take  --rank R --world W --id-file F  after their arguments: rank R of W processes (one per GPU; rank R
+//   uses GPU R % the GPUs present), sharded by Camera::Render_*(..., comm) over rt_hip_comm_* (RCCL).  Rank 0 writes the communicator's 128-byte id
+//   to F, the others wait for it; every rank ends with the whole picture, rank 0 writes it.
 //   layouts apples   <out.ppm> [resolution]                                     Layout1_Apples-like: textured mesh from
 //                                                                               RotationalSurfaceToMesh_Texture, textured +
 //                                                                               bump-mapped planes, anti-aliased render
@@ -15,8 +20,11 @@
 // Textures: the reference reads JPEG through OpenCV; here the images are synthetic (or binary PPM via Image::ReadPPM).
 #include "../ray_tracing_amd/host/rt_host.hpp"
 
+#include <chrono>
 #include <cstdlib>
 #include <iostream>
+#include <memory>
+#include <thread>
 
 using namespace rt::host;
 
@@ -30,12 +38,53 @@ static Image checker(uint32_t rows, uint32_t cols, uint32_t cell, const uint8_t 
   return im;
 }
 
+// --rank R --world W --id-file F anywhere after the positional arguments; removed from argv
+struct Shard { int rank = 0, world = 0; std::string id_file; };
+static Shard take_shard_options(int &argc, char **argv)
+{
+  Shard s; int out = 0;
+  for (int i = 0; i < argc; i++) {
+    const std::string a = argv[i];
+    if (a == "--rank" && i + 1 < argc) s.rank = std::atoi(argv[++i]);
+    else if (a == "--world" && i + 1 < argc) s.world = std::atoi(argv[++i]);
+    else if (a == "--id-file" && i + 1 < argc) s.id_file = argv[++i];
+    else argv[out++] = argv[i];
+  }
+  argc = out;
+  return s;
+}
+static int gpu_of_rank(int rank) { int n = 1; if (rt_hip_device_count(&n) != 0 || n < 1) n = 1; return rank % n; }
+// the communicator of this rank: rank 0 makes the id and leaves it in the file (written beside it, then renamed), the others pick it up
+static std::unique_ptr<Comm> make_comm(Context &gpu, const Shard &s)
+{
+  if (s.world < 1) return nullptr;
+  if (s.id_file.empty()) throw std::runtime_error("--world needs --id-file");
+  Comm::Id id{};
+  if (s.rank == 0) {
+    id = Comm::UniqueId();
+    const std::string tmp = s.id_file + ".part";
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f || std::fwrite(id.data(), 1, id.size(), f) != id.size()) throw std::runtime_error("cannot write " + tmp);
+    std::fclose(f);
+    std::rename(tmp.c_str(), s.id_file.c_str());
+  } else {
+    for (int tries = 0;; tries++) {
+      if (FILE *f = std::fopen(s.id_file.c_str(), "rb")) { const size_t n = std::fread(id.data(), 1, id.size(), f); std::fclose(f); if (n == id.size()) break; }
+      if (tries > 600) throw std::runtime_error("no communicator id in " + s.id_file);
+      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+  }
+  return std::unique_ptr<Comm>(new Comm(gpu, id, s.rank, s.world));
+}
+
 static int focusing(int argc, char **argv)
 {
+  const Shard sh = take_shard_options(argc, argv);
   if (argc < 4) { std::cerr << "usage: layouts focusing <obj> <out.ppm> [resolution] [spp]\n"; return 2; }
   const int res = argc > 4 ? std::atoi(argv[4]) : 100;
   const uint32_t spp = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 100;
-  Context gpu(0);
+  Context gpu(gpu_of_rank(sh.rank));
+  std::unique_ptr<Comm> comm = make_comm(gpu, sh);
   Scene scene(0.5);                                                                                     // Layout.h:138
   scene.AddInftyPlane(Point3D(0, 0, 0), Point3D(0, 0, 1), Material(_PLASTIC_), Colour(255, 255, 255));  // :140-142
   scene.AddInftyPlane(Point3D(10, 0, 0), Point3D(-1, 0, 0), Material(_PLASTIC_), Colour(0, 0, 0));      // :144-146
@@ -44,8 +93,29 @@ static int focusing(int argc, char **argv)
   scene.AddAreaLight(Point3D(-10, 20, 20), 1, 10, 10);                                                  // :155
   Camera camera(Point3D(-10, 0, 1.5), Point3D(1, 0, 0), Point3D(0, -1, 0), 10, 6.4, 4.8, res, 1);       // :157
   camera.seed = 1;
-  camera.Render_Focusing(gpu, scene, 0.1, Colour(200, 200, 200), spp);                                  // :159
-  camera.WritePPM(argv[3]);
+  if (comm) camera.Render_Focusing(gpu, scene, *comm, 0.1, Colour(200, 200, 200), spp);                 // the sample loop over the ranks
+  else camera.Render_Focusing(gpu, scene, 0.1, Colour(200, 200, 200), spp);                             // :159
+  if (sh.rank == 0) camera.WritePPM(argv[3]);
+  return 0;
+}
+
+static int raytracer(int argc, char **argv)
+{
+  const Shard sh = take_shard_options(argc, argv);
+  if (argc < 4) { std::cerr << "usage: layouts raytracer <obj> <out.ppm> [resolution] [depth] [--rank R --world W --id-file F]\n"; return 2; }
+  const int res = argc > 4 ? std::atoi(argv[4]) : 100, depth = argc > 5 ? std::atoi(argv[5]) : 3;
+  Context gpu(gpu_of_rank(sh.rank));
+  std::unique_ptr<Comm> comm = make_comm(gpu, sh);
+  Scene scene(0.5);
+  scene.AddInftyPlane(Point3D(0, 0, 0), Point3D(0, 0, 1), Material(_PLASTIC_), Colour(255, 255, 255));
+  scene.AddInftyPlane(Point3D(10, 0, 0), Point3D(-1, 0, 0), Material(_PLASTIC_), Colour(0, 0, 0));
+  scene.ReadObjFile_Triangle(argv[2], Point3D(0, -1, 0), 0.0015, Material(_METAL_), Colour(241, 46, 24));
+  scene.ConstructBSPTree();
+  scene.AddAreaLight(Point3D(-10, 20, 20), 1, 0, 1);
+  Camera camera(Point3D(-10, 0, 1.5), Point3D(1, 0, 0), Point3D(0, -1, 0), 10, 6.4, 4.8, res, depth);
+  if (comm) camera.Render_RayTracer(gpu, scene, *comm, Colour(200, 200, 200));                          // the pixel loop of Camera.h:59-63 over the ranks
+  else camera.Render_RayTracer(gpu, scene, Colour(200, 200, 200));
+  if (sh.rank == 0) camera.WritePPM(argv[3]);
   return 0;
 }
 
@@ -89,11 +159,13 @@ static void Object_Cup2(Scene &scene, Point3D center, const Material &material, 
 
 static int wine(int argc, char **argv)
 {
+  const Shard sh = take_shard_options(argc, argv);
   if (argc < 3) { std::cerr << "usage: layouts wine <out.ppm> [resolution] [times] [photonNum] [oversampleTimes]\n"; return 2; }
   const int res = argc > 3 ? std::atoi(argv[3]) : 100, times = argc > 4 ? std::atoi(argv[4]) : 30;
   const uint32_t photonNum = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 50000, os = argc > 6 ? (uint32_t)std::atoi(argv[6]) : 100;
   const double eps = 1e-8;
-  Context gpu(0);
+  Context gpu(gpu_of_rank(sh.rank));
+  std::unique_ptr<Comm> comm = make_comm(gpu, sh);
   Scene scene(0.5);                                                                                     // Layout.h:239
   scene.AddInftyPlane({0, 0, 0}, {0, 0, 1}, Material(_RUBBER_), Colour(140, 100, 60));                  // :241-251 (texture_wood / texture6 left out)
   scene.AddInftyPlane({10, 0, 0}, {-1, 0, 0}, Material(_PLASTIC_), Colour(90, 90, 110));
@@ -112,8 +184,10 @@ static int wine(int argc, char **argv)
   scene.AddAreaLight({-10, 25, 25}, 2, 2, 5);                                                           // :289
   Camera camera({-23.5, 27.5, 24}, {2.9, -3, -2}, {-1, -1, 0}, 15, 8, 6, res, 8);                       // :291
   camera.seed = 1;
-  camera.Render_PhotonMapper_Antialiasing(gpu, scene, times, Colour(0, 0, 0), photonNum, os);          // :299
-  camera.WritePPM(argv[2]);
+  if (comm) camera.Render_PhotonMapper(gpu, scene, *comm, times, Colour(0, 0, 0), photonNum);          // Render_PhotonMapper, the photons of a pass over the ranks
+  else if (os == 0) camera.Render_PhotonMapper(gpu, scene, times, Colour(0, 0, 0), photonNum);          // (oversampleTimes 0: the plain driver, Camera.h:291-313)
+  else camera.Render_PhotonMapper_Antialiasing(gpu, scene, times, Colour(0, 0, 0), photonNum, os);     // :299
+  if (sh.rank == 0) camera.WritePPM(argv[2]);
   size_t masked = 0; for (uint8_t m : camera.edge_mask()) masked += m;
   std::cout << camera.width() << "x" << camera.height() << ", " << scene.NumObjects() << " objects, " << masked << " pixels re-sampled\n";
   return 0;
@@ -156,10 +230,11 @@ int main(int argc, char **argv)
   try {
     const std::string what = argc > 1 ? argv[1] : "";
     if (what == "focusing") return focusing(argc, argv);
+    if (what == "raytracer") return raytracer(argc, argv);
     if (what == "apples") return apples(argc, argv);
     if (what == "wine") return wine(argc, argv);
     if (what == "room") return room(argc, argv);
-    std::cerr << "usage: layouts focusing|apples|wine|room ...\n";
+    std::cerr << "usage: layouts focusing|raytracer|apples|wine|room ...\n";
     return 2;
   } catch (const std::exception &e) { std::cerr << "error: " << e.what() << "\n"; return 1; }
 }

@@ -385,6 +385,16 @@ int rt_hip_comm_all_gather(rt_hip_comm *comm, const void *d_send, void *d_recv, 
 int rt_hip_comm_all_reduce_sum_f64(rt_hip_comm *comm, double *d_buf, size_t n, void *stream);
 int rt_hip_comm_destroy(rt_hip_comm *comm);
 
+/* Device buffers for a host that holds no HIP headers (ray_tracing_amd/host/rt_host.hpp: the sharded Camera::Render_* keep a rank's shard and the
+ * gathered frame on the GPU between the render, the collective and rt_hip_tiles_to_frame_dev).  No counterpart in the reference (one process, host
+ * memory only): plain hipMalloc / hipFree / hipMemset / hipMemcpy on the context's device.  upload / download are synchronous; download waits for
+ * everything enqueued on the device before it copies. */
+int rt_hip_device_alloc(rt_hip_ctx *ctx, size_t bytes, void **d_ptr);
+int rt_hip_device_free(rt_hip_ctx *ctx, void *d_ptr);
+int rt_hip_device_zero(rt_hip_ctx *ctx, void *d_ptr, size_t bytes);
+int rt_hip_device_upload(rt_hip_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int rt_hip_device_download(rt_hip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+
 /* Per-kernel device time, measured with hipEvents recorded on the caller's stream around every
  * kernel launch of this scene while profiling is on (rt_hip_set_profiling).  Index = RT_HIP_K_*. */
 #define RT_HIP_K_PRIMARY        0   /* camera/lens ray generation + closest hit (level 0) */

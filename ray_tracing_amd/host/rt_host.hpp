@@ -98,6 +98,38 @@ class Context {                  // one GPU
 };
 
 // CObjMesh, Parser.h:9-82 (token loop of LoadObjFile restated; only v / vt / vn / f are read)
+// One rank of a multi-GPU render (one process per GPU, RCCL over xGMI behind rt_hip_comm_*).  The reference has no counterpart: its only
+// parallelism is the OpenMP pixel loop of Camera.h:59-63, which the Camera::Render_*(..., comm) overloads below split over the ranks.
+//   rank 0:      auto id = Comm::UniqueId();   ... hand the 128 bytes to the other ranks (file, socket, MPI, launcher) ...
+//   every rank:  Comm comm(gpu, id, rank, world);       // collective: returns when all ranks have called
+class Comm {
+ public:
+  typedef std::array<unsigned char, RT_HIP_COMM_ID_BYTES> Id;
+  static Id UniqueId() { Id id{}; check(rt_hip_comm_unique_id(id.data()), "rt_hip_comm_unique_id"); return id; }
+  Comm(Context &ctx, const Id &id, int rank, int world) : ctx_(ctx.get()) { check(rt_hip_comm_create(ctx.get(), id.data(), rank, world, &c_), "rt_hip_comm_create"); rank_ = rank; world_ = world; }
+  explicit Comm(Context &ctx) : ctx_(ctx.get()) { check(rt_hip_comm_create(ctx.get(), nullptr, 0, 1, &c_), "rt_hip_comm_create"); }     // a single rank: no RCCL needed
+  ~Comm() { rt_hip_comm_destroy(c_); }
+  Comm(const Comm &) = delete; Comm &operator=(const Comm &) = delete;
+  int rank() const { return rank_; }
+  int world() const { return world_; }
+  rt_hip_comm *get() const { return c_; }
+  rt_hip_ctx *ctx() const { return ctx_; }
+ private:
+  rt_hip_ctx *ctx_ = nullptr; rt_hip_comm *c_ = nullptr; int rank_ = 0, world_ = 1;
+};
+// a device buffer of the C ABI's (the host layer includes no HIP header)
+class DeviceBuffer {
+ public:
+  DeviceBuffer(rt_hip_ctx *ctx, size_t bytes) : ctx_(ctx), bytes_(bytes) { check(rt_hip_device_alloc(ctx, bytes, &p_), "rt_hip_device_alloc"); check(rt_hip_device_zero(ctx, p_, bytes), "rt_hip_device_zero"); }
+  ~DeviceBuffer() { rt_hip_device_free(ctx_, p_); }
+  DeviceBuffer(const DeviceBuffer &) = delete; DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  void *get() const { return p_; }
+  size_t bytes() const { return bytes_; }
+  void download(void *dst, size_t n) const { check(rt_hip_device_download(ctx_, dst, p_, n), "rt_hip_device_download"); }
+ private:
+  rt_hip_ctx *ctx_; void *p_ = nullptr; size_t bytes_;
+};
+
 struct ObjMesh {
   struct Tuple { int pointIndex, texCoordsIndex, normIndex; };
   std::vector<Point3D> points, normals;
@@ -560,6 +592,82 @@ class Camera {                   // CCamera, Camera.h:14-51
     rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.clear();
     check(rt_hip_render_focusing(scene.Device(ctx), &cam_, &p, rgb_.data()), "rt_hip_render_focusing");
     for (double &c : rgb_) c = std::min(255.0, c);        // the running clamp of Colour.h:41-47, applied once
+    to_picture();
+  }
+  // ---- the same renders over the ranks of a communicator (one process per GPU).  Every rank ends with the whole picture. ----
+  // Render_RayTracer: the pixel loop of Camera.h:59-63 split by interleaved 128x64-pixel super-tiles (rank r renders super-tiles r, r + world, ...:
+  // every rank gets the same mix of cheap and expensive image regions), the shards all-gathered, put back into raster order on the GPU.
+  // Bit-identical to the single-GPU call.
+  void Render_RayTracer(Context &ctx, Scene &scene, Comm &comm, Colour background = Colour(0, 0, 0))
+  {
+    rt_hip_params p = params(background);
+    p.tile_offset = (uint32_t)comm.rank(); p.tile_stride = (uint32_t)comm.world();
+    if (comm.world() == 1) { p.tile_offset = 0; p.tile_stride = 0; }
+    const size_t n = (size_t)w_ * h_;
+    rgb_.assign(n * 3, 0.0); prim_.assign(n, -1);
+    uint32_t total = 0, per_rank = 0;
+    check(rt_hip_tile_shard_info(&cam_, (uint32_t)comm.world(), &total, &per_rank), "rt_hip_tile_shard_info");
+    const size_t slots = (size_t)per_rank * 8192, W = (size_t)comm.world();
+    rt_hip_scene *dev = scene.Device(ctx);
+    if (comm.world() == 1) {          // one rank: the frame is already in raster order; the gather is a copy (through RCCL when the communicator has one)
+      DeviceBuffer d_rgb(comm.ctx(), n * 24), d_id(comm.ctx(), n * 4), g_rgb(comm.ctx(), n * 24), g_id(comm.ctx(), n * 4);
+      check(rt_hip_render_whitted_dev(dev, &cam_, &p, (double *)d_rgb.get(), (int32_t *)d_id.get(), nullptr), "rt_hip_render_whitted_dev");
+      check(rt_hip_comm_all_gather(comm.get(), d_rgb.get(), g_rgb.get(), n * 24, nullptr), "rt_hip_comm_all_gather");
+      check(rt_hip_comm_all_gather(comm.get(), d_id.get(), g_id.get(), n * 4, nullptr), "rt_hip_comm_all_gather");
+      g_rgb.download(rgb_.data(), n * 24); g_id.download(prim_.data(), n * 4);
+    } else {
+      DeviceBuffer s_rgb(comm.ctx(), slots * 24), s_id(comm.ctx(), slots * 4), g_rgb(comm.ctx(), W * slots * 24), g_id(comm.ctx(), W * slots * 4);
+      DeviceBuffer f_rgb(comm.ctx(), n * 24), f_id(comm.ctx(), n * 4);
+      check(rt_hip_render_whitted_dev(dev, &cam_, &p, (double *)s_rgb.get(), (int32_t *)s_id.get(), nullptr), "rt_hip_render_whitted_dev");
+      check(rt_hip_comm_all_gather(comm.get(), s_rgb.get(), g_rgb.get(), slots * 24, nullptr), "rt_hip_comm_all_gather");
+      check(rt_hip_comm_all_gather(comm.get(), s_id.get(), g_id.get(), slots * 4, nullptr), "rt_hip_comm_all_gather");
+      check(rt_hip_tiles_to_frame_dev(&cam_, (uint32_t)comm.world(), g_rgb.get(), slots * 24, 24, f_rgb.get(), nullptr), "rt_hip_tiles_to_frame_dev");
+      check(rt_hip_tiles_to_frame_dev(&cam_, (uint32_t)comm.world(), g_id.get(), slots * 4, 4, f_id.get(), nullptr), "rt_hip_tiles_to_frame_dev");
+      f_rgb.download(rgb_.data(), n * 24); f_id.download(prim_.data(), n * 4);
+    }
+    to_picture();
+  }
+  // Render_Focusing: the sample loop of Camera.h:187-192 split over the ranks (rank r takes a contiguous slice of the spp lens samples; the
+  // sampler is keyed by (pixel, sample), so the slices are the single-GPU samples), the un-clamped sums all-reduced, one clamp at the end
+  // (= the reference's running clamp: every term is >= 0).  Equal to the single-GPU picture up to the order of the additions (<= 1e-12).
+  void Render_Focusing(Context &ctx, Scene &scene, Comm &comm, double radius, Colour background = Colour(0, 0, 0), uint32_t spp = 100)
+  {
+    rt_hip_params p = params(background);
+    p.spp = spp; p.lens_radius = radius;
+    const uint32_t W = (uint32_t)comm.world(), r = (uint32_t)comm.rank(), per = spp / W, extra = spp % W;
+    p.sample_first = r * per + std::min(r, extra); p.sample_count = per + (r < extra ? 1u : 0u);
+    const size_t n = (size_t)w_ * h_;
+    rgb_.assign(n * 3, 0.0); prim_.clear();
+    DeviceBuffer d_rgb(comm.ctx(), n * 24);
+    if (p.sample_count) check(rt_hip_render_focusing_dev(scene.Device(ctx), &cam_, &p, (double *)d_rgb.get(), nullptr), "rt_hip_render_focusing_dev");
+    check(rt_hip_comm_all_reduce_sum_f64(comm.get(), (double *)d_rgb.get(), n * 3, nullptr), "rt_hip_comm_all_reduce_sum_f64");
+    d_rgb.download(rgb_.data(), n * 24);
+    for (double &c : rgb_) c = std::min(255.0, c);
+    to_picture();
+  }
+  // Render_PhotonMapper: every rank runs the (deterministic) eye pass and holds the same hit points; a pass's photons are split by index
+  // (rt_hip_ppm_trace(first, count)), the per-hit-point sums (M, tau) all-reduced, and every rank applies the same RadianceEvaluation
+  // (PhotonMapper.h:357-376).  Photon counts are exact; tau up to the order of the additions.
+  void Render_PhotonMapper(Context &ctx, Scene &scene, Comm &comm, int times, Colour background = Colour(0, 0, 0), uint32_t photonNum = 50000)
+  {
+    rt_hip_params p = params(background);
+    rt_hip_ppm *m = nullptr;
+    check(rt_hip_ppm_begin(scene.Device(ctx), &cam_, &p, photonNum, (uint32_t)times, &m), "rt_hip_ppm_begin");
+    uint64_t hp = 0, per_pass = 0, seg = 0, hits = 0;
+    int rc = rt_hip_ppm_info(m, &hp, &per_pass, &seg, &hits);
+    const uint64_t W = (uint64_t)comm.world(), r = (uint64_t)comm.rank(), per = per_pass / W, extra = per_pass % W;
+    const uint64_t first = r * per + std::min(r, extra), count = per + (r < extra ? 1 : 0);
+    for (int t = 0; t < times && !rc; t++) {
+      if (count) rc = rt_hip_ppm_trace(m, (uint32_t)t, first, count, nullptr);
+      double *acc = nullptr; uint64_t nacc = 0;
+      if (!rc) rc = rt_hip_ppm_accumulators(m, &acc, &nacc);
+      if (!rc) rc = rt_hip_comm_all_reduce_sum_f64(comm.get(), acc, (size_t)nacc, nullptr);
+      if (!rc) rc = rt_hip_ppm_update(m, nullptr);
+    }
+    rgb_.assign((size_t)w_ * h_ * 3, 0.0); prim_.clear();
+    if (!rc) rc = rt_hip_ppm_resolve(m, rgb_.data());
+    rt_hip_ppm_end(m);
+    check(rc, "Render_PhotonMapper over a communicator");
     to_picture();
   }
   // Render_RayTracer_Antialiasing, Camera.h:83-169: G-buffer pass, Laplacian edge mask, oversampleTimes jittered rays

@@ -76,3 +76,29 @@ def test_layout6_room_program(ctx, tmp_path):
     img = _read_ppm(out)
     assert img.shape == (60, 80, 3) and img.std() > 10
     assert int(r.stdout.split(",")[1].split()[0]) > 100
+
+
+def _run(args, env=None, timeout=300):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([BIN] + args, capture_output=True, text=True, timeout=timeout, env=e)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+@pytest.mark.parametrize("force_rccl", ["0", "1"])
+def test_cpp_host_shards_over_a_communicator(ctx, tmp_path, force_rccl):
+    """The C++ host's own sharded renders (rt::host::Camera::Render_RayTracer / Render_Focusing / Render_PhotonMapper over a Comm: the loop of
+    Camera.h:59-63 split without any Python): a communicator of ONE rank -- two RCCL ranks cannot share the one GPU of the test box -- once as the
+    plain short cut and once with every collective going through RCCL (RT_HIP_COMM_FORCE_RCCL=1); the pictures must equal the unsharded program's
+    bit for bit.  (More than one rank: tests/test_gpu_tiles.py reassembles the same tile shards, sample slices and photon ranges through the same
+    entry points; an N-GPU run is the driver's.)"""
+    env = {"RT_HIP_COMM_FORCE_RCCL": force_rccl}
+    for what, args in (("raytracer", [scenes.ICOSA_OBJ, None, "40", "3"]), ("focusing", [scenes.ICOSA_OBJ, None, "20", "4"]), ("wine", [None, "12", "2", "800", "0"])):
+        plain, shard = str(tmp_path / (what + "_plain.ppm")), str(tmp_path / (what + "_shard.ppm"))
+        idf = str(tmp_path / (what + force_rccl + ".id"))
+        _run([what] + [plain if a is None else a for a in args])
+        _run([what] + [shard if a is None else a for a in args] + ["--rank", "0", "--world", "1", "--id-file", idf], env=env)
+        a, b = _read_ppm(plain), _read_ppm(shard)
+        assert a.shape == b.shape and (a == b).all(), what
+        assert a.std() > 5, what                                      # a picture, not a constant frame
