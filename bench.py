@@ -635,7 +635,7 @@ def other_config(name, args, D, torch, rta, W, ctx, short, once=False):
                "passes_timed": passes, "s_per_step": round(dt, 4), "photon_segments_per_pass": int(segs / passes), "rays": int(segs / passes),
                "Mrays_per_s": round(segs / passes / dt / 1e6, 2), "s_per_pass_at_10M_photons": round(dt * 1e7 / info["photons_per_pass"], 3),
                "extrapolated": info["photons_per_pass"] != 10000000, "parallelism": "photon split + all-reduce of (M, tau) per hit point" if world > 1 else "1 GPU"}
-        kernel = "k_ppm_trace"
+        kernel = "k_ppm_bounce"           # the per-bounce launches (their counters: averages over the launches of one pass, instructions and cycles alike)
     pmc = read_traffic(kernel + ":" + name) or read_traffic(kernel)
     if pmc.get("SQ_INSTS_VALU") and pmc.get("kernel_cycles"):
         # (both figures from the same profiled run: instructions and GRBM cycles of the kernel; the mix weights the cycles per instruction)
