@@ -394,6 +394,9 @@ __device__ RT_SOLVE_INLINE int pairs_solve(const DevScene &sc, WaveLds *lds, Pai
 {
   const int lane = threadIdx.x & 63;
   const int nb = n < 64 ? n : 64;
+#ifdef RT_SOLVE_STATS
+  int my_steps = 0, my_kind = -1;
+#endif
   if (lane < nb) {
     const int src = Q.owner[lane], id = Q.obj[lane];
     const RayLds &gr = lds->rays[src];
@@ -410,7 +413,17 @@ __device__ RT_SOLVE_INLINE int pairs_solve(const DevScene &sc, WaveLds *lds, Pai
       h = rotational_solve(R, o, d, record);                         // the box test was the condition for queueing
     }
     Q.t[lane] = h.t; Q.u[lane] = h.u; Q.v[lane] = h.v;
+#ifdef RT_SOLVE_STATS
+    my_steps = h.steps; my_kind = sc.obj_type[id] == 6 ? 0 : 1;
+#endif
   }
+#ifdef RT_SOLVE_STATS
+  for (int kind = 0; kind < 2; kind++) {
+    int mine = my_kind == kind ? my_steps : 0, mx = mine, sum = mine;
+    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, __shfl_xor(mx, off, 64)); sum += __shfl_xor(sum, off, 64); }
+    if (lane == 0 && mx) { atomicAdd(&g_solve_steps[4 + 2 * kind], 64ull * mx); atomicAdd(&g_solve_steps[5 + 2 * kind], (unsigned long long)sum); }
+  }
+#endif
   __builtin_amdgcn_wave_barrier();
   return nb;
 }

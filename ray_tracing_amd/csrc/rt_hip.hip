@@ -515,6 +515,15 @@ __device__ __forceinline__ void stamp(unsigned int wave, int which, int kernel =
 {
   if ((threadIdx.x & 63) == 0 && wave < RT_MAX_STAMPS) g_stamps[2 * RT_MAX_STAMPS * kernel + 2 * wave + which] = wall_clock64();
 }
+#ifdef RT_SOLVE_STATS
+extern "C" int rt_hip_debug_read_solve_steps(unsigned long long *out, int reset)
+{
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_solve_steps), 8 * 8, 0, hipMemcpyDeviceToHost));
+  if (reset) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_solve_steps), z, sizeof z, 0, hipMemcpyHostToDevice)); }
+  return RT_HIP_OK;
+}
+#endif
 #ifdef RT_TIMERS
 extern "C" int rt_hip_debug_read_timers(unsigned long long *out, int reset)
 {

@@ -31,11 +31,28 @@ struct DRotational {
 };
 
 constexpr int kMaxStepNum = 10;          // Object.h:831
+// Diagnostic build only (-DRT_SOLVE_STATS): Newton steps as the waves run them ([0] patch, [2] revolution: steps x 64) and as the lanes
+// need them ([1], [3]: lanes active in each step); the ratio is the lock-step efficiency of the solve loops.
+#if defined(RT_SOLVE_STATS) && defined(__HIPCC__)
+__device__ unsigned long long g_solve_steps[8];   // [4..7]: the same per batch of pairs if every lane ran its seeds without waiting for the others (64 x the longest lane, all lanes)
+#endif
+#if defined(RT_SOLVE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define RT_SOLVE_LANE_STEPS(h) (h).steps++;
+#define RT_SOLVE_COUNT(k) { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(m_)) { atomicAdd(&g_solve_steps[k], 64ull); atomicAdd(&g_solve_steps[k + 1], (unsigned long long)__builtin_popcountll(m_)); } }
+#else
+#define RT_SOLVE_COUNT(k)
+#define RT_SOLVE_LANE_STEPS(h)
+#endif
 constexpr double kMinStepLen = 1e-8;     // :832 (= eps)
 constexpr double kMaxDeviation = 0.3;    // :833
 constexpr double kPiRef = 3.1415926535;  // Geometry.h:13
 
-struct ParamHit { double t, u, v; };     // t = Dist(hit point, ray origin): what the scene compares (Scene.h:74); kMiss = none
+struct ParamHit {
+  double t, u, v;
+#ifdef RT_SOLVE_STATS
+  int steps = 0;
+#endif
+};     // t = Dist(hit point, ray origin): what the scene compares (Scene.h:74); kMiss = none
 
 RT_HD V3 lerp3(V3 a, V3 b, double s) { return a * (1 - s) + b * s; }          // P*(1-s) + Q*s, Bezier.h:33,121-127
 RT_HD V3 cubic3(V3 p0, V3 p1, V3 p2, V3 p3, double s)
@@ -121,6 +138,7 @@ RT_HD ParamHit bezier_hit(const DBezier &B, V3 o, V3 d)
 template <class BZ>
 RT_HD ParamHit bezier_solve(const BZ &B, const double (*seed)[3], V3 o, V3 d, bool first_only)
 {
+  ParamHit h; h.t = kMiss; h.u = kInfty; h.v = kInfty;
   const V3 center = mk(B.center[0], B.center[1], B.center[2]);
   double cur_u = kInfty, cur_v = kInfty, cur_t = kInfty;
   bool have = false;
@@ -131,6 +149,8 @@ RT_HD ParamHit bezier_solve(const BZ &B, const double (*seed)[3], V3 o, V3 d, bo
     double t = dist(mk(seed[k][0], seed[k][1], seed[k][2]), o);
     double pt = kMiss, pu = kMiss, pv = kMiss;                     // the iterate before (t, u, v)
     for (int step = 0; step < kMaxStepNum; step++) {
+      RT_SOLVE_COUNT(0)
+      RT_SOLVE_LANE_STEPS(h)
       V3 S, dPu, dPv; bez_eval(B, u, v, S, dPu, dPv);
       double tp, up, vp; newton_step(d, o, center, S, dPu, dPv, t, u, v, tp, up, vp);
       if (up < -kMaxDeviation || up > 1 + kMaxDeviation || vp < -kMaxDeviation || vp > 1 + kMaxDeviation || tp < -kMaxDeviation) break;
@@ -143,7 +163,6 @@ RT_HD ParamHit bezier_solve(const BZ &B, const double (*seed)[3], V3 o, V3 d, bo
       u = up; v = vp; t = tp;
     }
   }
-  ParamHit h; h.t = kMiss; h.u = kInfty; h.v = kInfty;
   if (have) { h.t = dist(center + bez_point(B, cur_u, cur_v), o); h.u = cur_u; h.v = cur_v; }
   return h;
 }
@@ -388,7 +407,10 @@ RT_HD ParamHit rotational_solve(const DRotational &R, V3 o, V3 d, bool record)
   for (int i = 0; i <= R.u_sample_num; i++) {
     double u = i * u_int, v, t;
     if (!rot_seed(R, u, o, d, t, v)) continue;
+    double pt = kMiss, pu = kMiss, pv = kMiss;                     // the iterate before (t, u, v)
     for (int step = 0; step < kMaxStepNum; step++) {
+      RT_SOLVE_COUNT(2)
+      RT_SOLVE_LANE_STEPS(h)
       V3 S, dPu, dPv; rot_eval(R, u, v, S, dPu, dPv);
       double tp, up, vp; newton_step(d, o, center, S, dPu, dPv, t, u, v, tp, up, vp);
       if (up < -kMaxDeviation || up > 1 + kMaxDeviation || tp < -kMaxDeviation) break;
@@ -396,6 +418,11 @@ RT_HD ParamHit rotational_solve(const DRotational &R, V3 o, V3 d, bool record)
         have = true;
         if (tp < cur_t) { cur_u = up; cur_v = vp; cur_t = tp; break; }
       }
+#ifndef RT_NO_REPEAT_EXIT
+      // iterates that repeat (x' == x, or x' == the iterate before x) would be examined again against the same cur_t: the seed is done
+      if ((tp == t && up == u && vp == v) || (tp == pt && up == pu && vp == pv)) break;
+      pt = t; pu = u; pv = v;
+#endif
       u = up; v = vp; t = tp;
     }
   }
