@@ -87,6 +87,11 @@ def main():
             cur["cnt"] += classify(mo.group(1))
         i += 1
     # top-level code is split at every depth-1 loop it lies between, so that setup / confirmation / shading can be told apart
+    # --blocks LOOP[,LOOP...]: the basic blocks of these loops are listed one by one (a loop nest the compiler has folded into one loop --
+    # the cull step with its hand-back rounds -- is told apart by block)
+    by_block = set()
+    if "--blocks" in sys.argv:
+        by_block = set(sys.argv[sys.argv.index("--blocks") + 1].split(","))
     regions = collections.OrderedDict()
     seg = 0
     last_top_loop = None
@@ -100,6 +105,9 @@ def main():
                 top = parents[top]
             if top != last_top_loop:
                 last_top_loop = top; seg += 1
+            if b["loop"] in by_block and not b["hdr"]:
+                key = b["loop"] + ":" + b["label"].replace(".L", "")
+                parents[key] = b["loop"]
         regions.setdefault(key, collections.Counter())
         regions[key] += b["cnt"]
     def depth_of(k):
