@@ -84,6 +84,10 @@ struct DevScene {
   const DPlane *planes; const DSphere *spheres; const DCircle *circles;
   const DBezier *beziers; const DRotational *rotationals;
   int32_t has_param;                            // the scene holds Bezier / rotational objects: kernels built with PARAM
+  // the Newton-solved objects numbered 0 .. n_rot + n_bez - 1 (pidx: a surface of revolution k is k, a patch k is n_rot + k), and the
+  // global (ray, object) queue of the deferred solves (rt_defer.inc; set per launch, NULL otherwise)
+  int32_t n_rot, n_bez; const int32_t *param_obj;   // param_obj[pidx] = object id
+  struct PairRec *gq_pairs; unsigned int *gq_count; unsigned int gq_region;   // object pidx owns slots [pidx * gq_region, (pidx + 1) * gq_region), gq_count[pidx] of them used
   const uint8_t *obj_type; const uint32_t *obj_index; const uint32_t *obj_mat; const double *obj_colour;
   int32_t n_objects;
   // textures (Object.h:69-74); obj_tex == NULL: no object of the scene has one
@@ -97,6 +101,10 @@ struct DevScene {
   double rbmin[3], rbmax[3];                    // root box (inflated); only used to order work, never for results
   float rbf_min[3], rbf_max[3];                 // the same in FP32, rounded outward: shadow rays that miss it skip the walk (trace_occluded)
 };
+
+// One deferred solve: `ray` names the ray (index of its node / photon), tag = pidx | sample << 8 | light << 20 (shadow rays), next = the
+// ray's previous pair (closest-hit queries fold their pairs in rt_defer.inc: k_closest_p3), n_seeds = filled by the solver's preparation pass.
+struct PairRec { uint32_t ray, tag, next, n_seeds; };
 
 struct Stats { unsigned long long rays, shadow_rays, node_visits, prim_tests, exact_tests, wave_nodes, wave_prims, pad; };
 
@@ -200,6 +208,7 @@ struct RayState {
   double best_u, best_v;            // surface parameters of the confirmed hit (PARAM kernels only)
   int mb_id; double mb_t, mb_u, mb_v; // the last non-triangle leaf object tested and its result: the reference re-solves an
                                       // object in every leaf that lists it (Scene.h:352), always with the same result
+  unsigned long long pq_mask;         // deferred solves (walk<.., GQ>): the Newton-solved objects (bit pidx) listed by the leaves this ray wanted
 };
 
 __device__ __forceinline__ double safe_inv(double x) { return (fabs(x) < 1e-30) ? ((x < 0) ? -1e30 : 1e30) : 1.0 / x; }
@@ -240,7 +249,7 @@ __device__ __forceinline__ void ray_setup_scaled(RayState &r, V3 o, V3 d, double
   r.inv = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   r.oi = mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
   r.bound = kMiss; r.best_t = kMiss; r.best_id = -1;
-  r.best_u = kInfty; r.best_v = kInfty; r.mb_id = -1; r.mb_t = kMiss; r.mb_u = kInfty; r.mb_v = kInfty;
+  r.best_u = kInfty; r.best_v = kInfty; r.mb_id = -1; r.mb_t = kMiss; r.mb_u = kInfty; r.mb_v = kInfty; r.pq_mask = 0ull;
   r.tmargin = 1e-6 * s;
   r.mscale = 1e-8 * s;
   r.gmin = 1e-6;
@@ -486,7 +495,9 @@ struct Deferred {
 // ANY = false: closest hit; confirmed hits go to r.best_t / r.best_id, r.bound prunes.
 // ANY = true : occlusion; `found` becomes true for a lane as soon as a confirmed hit satisfies occludes()
 //              (DEFER: as soon as a cull survivor MAY satisfy it; D.c1_id remembers which).
-template <bool ANY, bool DEFER, bool STATS, bool PARAM>
+// GQ = true (with PARAM = false): deferred solves -- a Newton-solved object listed by a leaf is only noted in r.pq_mask; the caller queues the
+// (ray, object) pairs after the walk (gq_push_closest / gq_push_occluded) and a kernel of its own solves them (rt_defer.inc).
+template <bool ANY, bool DEFER, bool STATS, bool PARAM, bool GQ = false>
 __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref, double fmargin,
                                      WaveLds *lds, Stats &st, Deferred &D, bool &found, bool record)
 {
@@ -754,6 +765,14 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
             const int prim = uni(recs[i].prim_id);
             const bool lane_on = want && !(ANY && found);
             if (STATS && lane_on) st.exact_tests++;
+            if constexpr (GQ) {
+              const int type = uni((int)sc.obj_type[prim]);
+              if (type == 5 || type == 6) {
+                const int pidx = uni((int)sc.obj_index[prim]) + (type == 6 ? sc.n_rot : 0);
+                if (lane_on) r.pq_mask |= 1ull << pidx;
+                continue;
+              }
+            }
             if constexpr (PARAM) {
               const int type = uni((int)sc.obj_type[prim]);
               if (type == 5 || type == 6) {
@@ -835,6 +854,14 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
           const int prim = uni(recs[i].prim_id);
           const bool lane_on = want && !(ANY && found);
           if (STATS && lane_on) st.exact_tests++;
+          if constexpr (GQ) {
+            const int type = uni((int)sc.obj_type[prim]);
+            if (type == 5 || type == 6) {
+              const int pidx = uni((int)sc.obj_index[prim]) + (type == 6 ? sc.n_rot : 0);
+              if (lane_on) r.pq_mask |= 1ull << pidx;
+              continue;
+            }
+          }
           double hu = kInfty, hv = kInfty;
           const double ht = lane_on ? leaf_other_hit<PARAM>(sc, r, r.o, r.d, prim, record, hu, hv) : kMiss;
           confirmed(ht, prim, lane_on, hu, hv);
@@ -861,7 +888,10 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
 
 // Closest hit of one ray per lane (CScene::FirstInterPt_BSPTree, Scene.h:85-91; FirstInterPt, Scene.h:62-83,
 // when the scene has no tree).  Result in r.best_t / r.best_id.  All lanes of the wave call this together.
-template <bool STATS, bool PARAM>
+// GQ (with PARAM = false): the Newton-solved objects are not solved here; r.pq_mask names the ones whose (ray, object) pair the caller
+// queues with gq_push_closest, and r.best_* is the closest hit among all other objects (with a tree; without one the caller folds in
+// object order, k_closest_p3).
+template <bool STATS, bool PARAM, bool GQ = false>
 __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, bool active, WaveLds *lds, Stats &st, bool record = true)
 {
   auto take = [&](double t, int id, double hu = kInfty, double hv = kInfty) {   // the update rule of Scene.h:74-79 (objects come in id order)
@@ -904,6 +934,22 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
       return;
     } else {
     for (int id = 0; id < sc.n_objects; id++) {
+      if constexpr (GQ) {
+        // a candidate replaces the best so far only if it is nearer by eps (Scene.h:74): solves whose hits lie beyond the best of the objects
+        // BEFORE this one cannot matter.  (The best so far lacks the Newton-solved objects before this one: fewer solves are skipped than
+        // in the in-place form above, the result is the same.)
+        const int type = uni((int)sc.obj_type[id]);
+        if (type == 5 || type == 6) {
+          const int k = uni((int)sc.obj_index[id]);
+          const double t_max = r.best_id >= 0 ? r.best_t : kMiss;
+          bool want;
+          if (type == 5) { const DRotational &R = sc.rotationals[k]; want = active && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, t_max) && rot_shells_may_matter(R, r.o, r.d, t_max); }
+          else { const DBezier &Z = sc.beziers[k]; want = active && param_may_matter(r, Z.pmin, Z.pmax, t_max); }
+          if (STATS && active) st.exact_tests++;
+          if (want) r.pq_mask |= 1ull << (k + (type == 6 ? sc.n_rot : 0));
+          continue;
+        }
+      }
       double hu, hv;
       double t = active ? object_hit<PARAM>(sc, id, r.o, r.d, record, hu, hv) : kMiss;
       if (STATS && active) st.exact_tests++;
@@ -924,7 +970,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
   if (inf_id >= 0) r.bound = inf_t + r.tmargin;
   Deferred D; D.c1_t = D.c2_t = D.c3_t = kMiss; D.c1_id = D.c2_id = -1; D.redo = false;
   bool dummy = false;
-  walk<false, true, STATS, PARAM>(sc, r, active, false, mk(0, 0, 0), 0.0, lds, st, D, dummy, record);
+  walk<false, true, STATS, PARAM, GQ>(sc, r, active, false, mk(0, 0, 0), 0.0, lds, st, D, dummy, record);
   // ---- confirm the survivors, all lanes together ----
   const bool h1 = active && D.c1_id >= 0, h2 = active && D.c2_id >= 0;
   double t1 = kMiss, t2 = kMiss;
@@ -944,8 +990,8 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
     RayState q = r;
     q.best_t = kMiss; q.best_id = -1; q.bound = (inf_id >= 0) ? inf_t + r.tmargin : kMiss;
     q.mb_id = -1;                            // the fast walk used the mailbox as a 'queued' mark only
-    walk<false, false, STATS, PARAM>(sc, q, redo, false, mk(0, 0, 0), 0.0, lds, st, D, dummy, record);
-    if (redo) { r.best_t = q.best_t; r.best_id = q.best_id; if (PARAM) { r.best_u = q.best_u; r.best_v = q.best_v; } }
+    walk<false, false, STATS, PARAM, GQ>(sc, q, redo, false, mk(0, 0, 0), 0.0, lds, st, D, dummy, record);
+    if (redo) { r.best_t = q.best_t; r.best_id = q.best_id; if (PARAM) { r.best_u = q.best_u; r.best_v = q.best_v; } if (GQ) r.pq_mask |= q.pq_mask; }
   }
 #endif
   if (active && !redo) {
@@ -962,7 +1008,9 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
 // Occlusion query of one ray per lane: is there a hit X with occludes() true (Scene.h:449, Light.h:66,91,147)?
 // t_limit: no hit beyond it can satisfy the predicate (kMiss if unbounded).  Shadow tests go through
 // FirstInterPt_Unrecorded (Light.h:65, 90, 146; Scene.h:448 record = false).
-template <bool STATS, bool PARAM, bool ROOT_TEST = true>
+// GQ (with PARAM = false): the answer covers every object but the Newton-solved ones; r.pq_mask names those whose pairs the caller queues
+// with gq_push_occluded for the rays that come back unoccluded.
+template <bool STATS, bool PARAM, bool ROOT_TEST = true, bool GQ = false>
 __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, bool active, bool has_ref, V3 ref, double t_limit,
                                                WaveLds *lds, Stats &st)
 {
@@ -1005,11 +1053,13 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
     for (int id = 0; id < sc.n_objects; id++) {
       const bool lane_on = active && !found;
       if (__ballot(lane_on) == 0ull) break;
+      if constexpr (GQ) { const int type = uni((int)sc.obj_type[id]); if (type == 5 || type == 6) continue; }   // (any object may occlude: the order does not matter)
       double hu, hv;
       double t = lane_on ? object_hit<PARAM>(sc, id, r.o, r.d, false, hu, hv) : kMiss;
       if (STATS && lane_on) st.exact_tests++;
       if (lane_on && t < kMiss && occludes(r.o, r.d, t, has_ref, ref)) found = true;
     }
+    if constexpr (GQ) { const int np = sc.n_rot + sc.n_bez; if (active && !found) r.pq_mask = np >= 64 ? ~0ull : ((1ull << np) - 1ull); }
     return found;
     }
   }
@@ -1029,7 +1079,7 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
   if (ROOT_TEST && __ballot(walk_on) == 0ull) return found;
   const double fmargin = 3.0 * (len(ref - r.o) + 1.0) * r.tmargin;
   Deferred D; D.c1_t = D.c2_t = D.c3_t = kMiss; D.c1_id = D.c2_id = -1; D.redo = false;
-  walk<true, true, STATS, PARAM>(sc, r, walk_on, has_ref, ref, fmargin, lds, st, D, found, false);
+  walk<true, true, STATS, PARAM, GQ>(sc, r, walk_on, has_ref, ref, fmargin, lds, st, D, found, false);
   // ---- confirm the survivor that stopped the walk ----
   const bool h1 = active && !pre && found && D.c1_id >= 0;
   bool ok = false;
@@ -1042,11 +1092,63 @@ __device__ __forceinline__ bool trace_occluded(const DevScene &sc, RayState &r, 
     if (STATS) { if (redo) st.pad++; if ((threadIdx.x & 63) == 0) st.pad += (1ull << 32); }
     bool f2 = false;
     RayState q = r; q.bound = t_limit; q.mb_id = -1;
-    walk<true, false, STATS, PARAM>(sc, q, redo, has_ref, ref, fmargin, lds, st, D, f2, false);
-    if (redo) found = f2;
+    walk<true, false, STATS, PARAM, GQ>(sc, q, redo, has_ref, ref, fmargin, lds, st, D, f2, false);
+    if (redo) { found = f2; if (GQ) r.pq_mask |= q.pq_mask; }
   }
 #endif
   return found;
+}
+
+// ---- deferred solves: the global (ray, object) queue (rt_defer.inc) -----------------------------------------------------------------
+// Every object has its own stretch of the queue, so that a solver launch works on ONE object (its data are wave-uniform: scalar loads, no
+// per-lane tables).  Returns the pair's slot (the new head of the ray's list) or `head`.
+__device__ __forceinline__ uint32_t gq_push(const DevScene &sc, bool push, int pidx, uint32_t ray, uint32_t tag, uint32_t head)
+{
+  const unsigned long long m = ballot64(push);
+  if (m == 0ull) return head;
+  const unsigned int lane = threadIdx.x & 63;
+  unsigned int base = 0;
+  if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(&sc.gq_count[pidx], (unsigned int)__popcll(m));
+  base = (unsigned int)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+  const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const unsigned int idx = base + (unsigned int)__popcll(m & below);
+  if (!push || idx >= sc.gq_region) return head;                 // (a launch is sized so that its rays cannot fill a stretch: never taken)
+  const unsigned int slot = (unsigned int)pidx * sc.gq_region + idx;
+  PairRec p; p.ray = ray; p.tag = tag; p.next = head; p.n_seeds = 0;
+  sc.gq_pairs[slot] = p;
+  return slot;
+}
+// the pairs of a closest-hit query (after trace_closest<.., GQ>).  With a tree the solves that cannot matter are skipped here, against the
+// final closest hit of the other objects: a Newton hit beyond it (by more than the tie window) changes nothing.
+__device__ __forceinline__ uint32_t gq_push_closest(const DevScene &sc, const RayState &r, bool active, uint32_t ray)
+{
+  uint32_t head = 0xFFFFFFFFu;
+  const int np = sc.n_rot + sc.n_bez;
+  const double t_max = r.best_id >= 0 ? r.best_t + r.tmargin : kMiss;
+  for (int pidx = 0; pidx < np; pidx++) {
+    bool want = active && ((r.pq_mask >> pidx) & 1ull);
+    if (ballot64(want) == 0ull) continue;
+    const bool bez = pidx >= sc.n_rot;
+    if (sc.has_tree) {
+      if (!bez) { const DRotational &R = sc.rotationals[pidx]; want = want && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, t_max) && rot_shells_may_matter(R, r.o, r.d, t_max); }
+      else { const DBezier &Z = sc.beziers[pidx - sc.n_rot]; want = want && param_may_matter(r, Z.pmin, Z.pmax, t_max); }
+    }
+    head = gq_push(sc, want, pidx, ray, (uint32_t)pidx, head);
+  }
+  return head;
+}
+// the pairs of an occlusion query that came back unoccluded (after trace_occluded<.., GQ>); tag_hi = sample << 8 | light << 20
+__device__ __forceinline__ void gq_push_occluded(const DevScene &sc, const RayState &r, bool open, double t_limit, uint32_t ray, uint32_t tag_hi)
+{
+  const int np = sc.n_rot + sc.n_bez;
+  for (int pidx = 0; pidx < np; pidx++) {
+    bool want = open && ((r.pq_mask >> pidx) & 1ull);
+    if (ballot64(want) == 0ull) continue;
+    const bool bez = pidx >= sc.n_rot;
+    if (!bez) { const DRotational &R = sc.rotationals[pidx]; want = want && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, t_limit) && rot_shells_may_matter(R, r.o, r.d, t_limit); }
+    else { const DBezier &Z = sc.beziers[pidx - sc.n_rot]; want = want && param_may_matter(r, Z.pmin, Z.pmax, t_limit); }
+    (void)gq_push(sc, want, pidx, ray, tag_hi | (uint32_t)pidx, 0xFFFFFFFFu);
+  }
 }
 
 // ---- shading ------------------------------------------------------------------------------------

@@ -107,6 +107,11 @@ struct rt_hip_scene {
   bool keep_uv = false;            // photon mapping eye pass: keep the (u, v) of every node's hit (k_shade overwrites them)
   bool one_sample = false;         // exactly one light and it takes one shadow ray per point: k_frame_direct has a loop-free form for it
   DevBuf uv[kMaxLevels];
+  // deferred Newton solves (rt_defer.inc): the global pair queue and the solver's per-batch buffers
+  DevBuf gq_pairs, gq_counts, gq_res, gq_rays, gq_uvh, gq_seeds, gq_seed_mask, gq_occ;
+  bool defer_fits = false;         // every Newton-solved object, profile sample and light sample has a bit in the masks of rt_defer.inc
+  unsigned int max_seeds = 1, shadow_samples = 1;   // largest uSampleNum + 1; shadow rays per shaded point (all lights)
+  uint64_t last_pairs = 0;         // (ray, object) pairs the last render queued (diagnostic)
   DevBuf aa_maps, aa_edges, aa_mask;   // anti-aliasing drivers: G-buffer maps, list of masked pixels, the mask when the caller keeps none
   uint64_t last_aa_edges = 0;
   // optional per-kernel timing (rt_hip_set_profiling)
@@ -741,8 +746,9 @@ __global__ void __launch_bounds__(1024) k_order(const unsigned char *flags, unsi
 
 // level 0: camera / lens ray generation (Camera.h:65-67, 189-190) + closest hit, one 8x8 pixel tile per wave
 template <bool STATS, bool PARAM>
+// gen_only: the rays are made and stored, their closest hits are found afterwards (closest_deferred, rt_defer.inc)
 __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_primary(DevScene sc, RenderArgs A, PathNode *nodes, const unsigned int *order,
-                                                                    unsigned char *shadow_flags, Stats *gstats)
+                                                                    unsigned char *shadow_flags, Stats *gstats, int gen_only)
 {
   __shared__ WaveLds s_lds[RT_WAVES];
   WaveLds *stack = &s_lds[threadIdx.x >> 6];
@@ -773,8 +779,8 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   }
   V3 d = unitize(unitize(cur - o));     // Camera.h:67 + CRay ctor (Geometry.h:253-254)
   RayState r; ray_setup(r, o, d, sc.coord_scale);
-  if (STATS && active) st.rays++;
-  trace_closest<STATS, PARAM>(sc, r, active, stack, st);
+  if (STATS && active && !gen_only) st.rays++;
+  if (!gen_only) trace_closest<STATS, PARAM>(sc, r, active, stack, st);
   if (active) {
     PathNode &nd = nodes[(uint64_t)wave * 64 + lane];     // level 0 is stored in tile order (see node_of_pixel)
     nd.o[0] = o.x; nd.o[1] = o.y; nd.o[2] = o.z; nd.d[0] = d.x; nd.d[1] = d.y; nd.d[2] = d.z;
@@ -1382,6 +1388,27 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   up(upload(s, planes, &D.planes)); up(upload(s, spheres, &D.spheres)); up(upload(s, circles, &D.circles));
   up(upload(s, beziers, &D.beziers)); up(upload(s, rots, &D.rotationals));
   D.has_param = (d->n_beziers || d->n_rotationals) ? 1 : 0;
+  D.n_rot = (int32_t)d->n_rotationals; D.n_bez = (int32_t)d->n_beziers; D.param_obj = nullptr; D.gq_pairs = nullptr; D.gq_count = nullptr; D.gq_region = 0;
+  if (D.has_param) {
+    std::vector<int32_t> pobj((size_t)D.n_rot + D.n_bez, -1);
+    for (uint32_t id = 0; id < d->n_objects; id++) {
+      if (types[id] == 5) pobj[index[id]] = (int32_t)id;
+      else if (types[id] == 6) pobj[(size_t)D.n_rot + index[id]] = (int32_t)id;
+    }
+    up(upload(s, pobj, &D.param_obj));
+    s->defer_fits = D.n_rot + D.n_bez <= 64 && d->n_lights < 4096;
+    s->max_seeds = 1; s->shadow_samples = 0;
+    for (uint32_t k = 0; k < d->n_rotationals; k++) {
+      if (d->rotationals[k].u_sample_num > 63) s->defer_fits = false;
+      s->max_seeds = std::max(s->max_seeds, (unsigned int)d->rotationals[k].u_sample_num + 1u);
+    }
+    for (uint32_t k = 0; k < d->n_lights; k++) {
+      const unsigned int sn = d->lights[k].type == RT_HIP_AREA_LIGHT ? (unsigned int)d->lights[k].sample_num : 1u;
+      if (sn * sn > 128u || sn > 11u) s->defer_fits = false;
+      s->shadow_samples += sn * sn;
+    }
+    for (int32_t v : pobj) if (v < 0) s->defer_fits = false;     // a surface no object uses: keep the in-place form
+  }
   up(upload(s, types, &D.obj_type)); up(upload(s, index, &D.obj_index)); up(upload(s, omat, &D.obj_mat));
   up(upload(s, colour, &D.obj_colour)); up(upload(s, mats, &D.materials)); up(upload(s, lights, &D.lights));
   if (rc != RT_HIP_OK) { std::string m = g_err; rt_hip_scene_destroy(s); return fail(rc, m); }
@@ -1403,6 +1430,7 @@ extern "C" int rt_hip_scene_share(rt_hip_scene *src, rt_hip_scene **out)
   s->ctx = src->ctx; ctx_retain(s->ctx); s->dev = src->dev; s->geo = src->geo;
   s->n_nodes = src->n_nodes; s->n_leaves = src->n_leaves; s->n_cull = src->n_cull; s->max_depth = src->max_depth;
   s->one_sample = src->one_sample; s->fan = src->fan;
+  s->defer_fits = src->defer_fits; s->max_seeds = src->max_seeds; s->shadow_samples = src->shadow_samples;
   *out = s;
   return RT_HIP_OK;
 }
@@ -1566,6 +1594,8 @@ extern "C" int rt_hip_camera_size(const rt_hip_camera *cam, int *w, int *h)
 
 static int godray_level(rt_hip_scene *s, PathNode *nodes, unsigned int n, const unsigned int *n_dev, hipStream_t st);   // rt_godray.inc
 
+#include "rt_defer.inc"
+
 // Levels of the ray tree once level 0 holds its n0 nodes with their closest hits (k_primary / k_primary_list):
 // shadow pass, shading + child rays, closest hit of the children, ... and the bottom-up composition.
 // order1: optional heavy-first order of the level-0 waves for the shadow pass.
@@ -1576,6 +1606,7 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
   RenderCounters *cnt = (RenderCounters *)s->counter.p;
   Stats *gs = stats ? s->ctx->d_stats : nullptr;
   const bool param = s->dev.has_param != 0;
+  const bool defer = defer_ok(s);      // Newton solves as kernels of their own (rt_defer.inc): every level's size is fetched, the solver's launches depend on counts anyway
   // cap[lv]: the host's bound on the size of level lv.  Level 0 is exact.  Below it the sizes are only known on the device
   // (cnt->level_n): level lv + 1 holds at most `fan` children per node of level lv (2 when some material both reflects and
   // refracts, else 1), the kernels are launched for that bound and their surplus blocks leave at once -- no read-back, no
@@ -1602,6 +1633,7 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
     if (depth_left > 1) {
       uint64_t bound = (uint64_t)s->fan * n;
       if (bound * sizeof(PathNode) > kLevelBudget) { bound = 2ull * n; fetch_next = true; }   // too large to run blind: learn the real size after this level
+      if (defer) fetch_next = true;
       if (bound > 0x7FFFFFFFull) return fail(RT_HIP_ENOMEM, "ray tree level too large");
       if (fetch_next && !exact[lv]) {
         // this level's own size is still a bound: settle it first so that the next level's array is sized from the real count
@@ -1615,14 +1647,16 @@ static int run_levels_from(rt_hip_scene *s, const RenderArgs &A, bool stats, hip
       next = (PathNode *)s->levels[lv + 1].p; next_cap = (unsigned int)bound;
     }
     PathNode *cur = (PathNode *)s->levels[lv].p;
-    if (lv > 0) {
+    if (lv > 0 && defer) { rc = closest_deferred(s, path_view(cur), n, stats, true, st); if (rc) return rc; }
+    else if (lv > 0) {
       ProfScope ps(s, RT_HIP_K_TRACE_NODES, st);
       RT_LAUNCH_SP(k_trace_nodes, stats, param, dim3(blocks_for(n)), st, s->dev, cur, n, n_dev, gs);
     }
     rc = s->lum.ensure((size_t)n * std::max(1, s->dev.n_lights) * sizeof(double)); if (rc) return rc;
     double *lum = (double *)s->lum.p;
     const bool direct = direct_rgb && lv == 0 && depth == 1;
-    if (s->dev.n_lights > 0) {
+    if (s->dev.n_lights > 0 && defer) { rc = shadow_deferred(s, A, cur, n, lum, stats, st); if (rc) return rc; }
+    else if (s->dev.n_lights > 0) {
       ProfScope ps(s, RT_HIP_K_SHADOW, st);
       const unsigned int *ord = (lv == 0) ? (const unsigned int *)order1 : nullptr;
       RT_LAUNCH_SP(k_shadow, stats, param, dim3(blocks_for(n)), st, s->dev, A, (const PathNode *)cur, n, n_dev, lum, ord, cnt, gs);
@@ -1795,7 +1829,8 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   // heavy-first order of the level-0 waves (only worth it with a tree)
   OrderBufs O;
   const int cam_depth = A.cam.depth < 1 ? 1 : A.cam.depth;
-  const bool direct = direct_rgb && cam_depth == 1 && s->dev.n_lights > 0 && !s->god && !s->keep_uv && !A.focusing && A.n_samples == 1;
+  const bool defer = defer_ok(s);
+  const bool direct = direct_rgb && cam_depth == 1 && s->dev.n_lights > 0 && !s->god && !s->keep_uv && !A.focusing && A.n_samples == 1 && !defer;
   // a depth-1 frame of a tiling this handle has rendered before: longest-first by the waves' last run times (k_cost_order)
   const uint64_t sig[6] = {n_waves, ((uint64_t)A.cam.W << 32) | (uint64_t)A.cam.H, ((uint64_t)A.tile_offset << 32) | A.tile_stride, A.pixel_first, A.pixel_count, (uint64_t)A.v_lo + 1};
   // (worth it from about six rounds of the GPU's 4,096 wave slots on: measured on C2, the full frame's 32,640 waves gain 3 %, a half frame's
@@ -1804,7 +1839,7 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   const bool cost_sized = cost_mode != 0 && (cost_mode == 2 || n_waves >= 6u * 4096u) && n_waves <= (1u << 18);
   const bool by_cost = direct && s->dev.has_tree && !stats && cost_sized && std::memcmp(sig, s->cost_sig, sizeof sig) == 0;
   // a launch that fits the wave slots twice over starts (nearly) all its waves at once: no order to compute
-  const bool ordered = s->dev.has_tree && (by_cost || !(direct && n_waves <= 2u * 4096u));
+  const bool ordered = !defer && s->dev.has_tree && (by_cost || !(direct && n_waves <= 2u * 4096u));
   if (ordered) {
     rc = s->order.ensure(order_bytes(n_waves)); if (rc) return rc;
     if (by_cost) {
@@ -1829,9 +1864,18 @@ static int run_levels(rt_hip_scene *s, const RenderArgs &A, bool stats, hipStrea
   }
   rc = s->levels[0].ensure(n0 * sizeof(PathNode)); if (rc) return rc;
   PathNode *L0 = (PathNode *)s->levels[0].p;
+  if (defer) {
+    {
+      ProfScope ps(s, RT_HIP_K_PRIMARY, st);
+      hipLaunchKernelGGL((k_primary<false, false>), dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, L0, (const unsigned int *)nullptr, (unsigned char *)nullptr, gs, 1);
+      HIP_TRY(hipGetLastError());
+    }
+    rc = closest_deferred(s, path_view(L0), (unsigned int)n0, stats, true, st); if (rc) return rc;
+    return run_levels_from(s, A, stats, st, n0, nullptr, A.n_primary * A.n_samples, direct_rgb, direct_id);
+  }
   {
     ProfScope ps(s, RT_HIP_K_PRIMARY, st);
-    RT_LAUNCH_SP(k_primary, stats, param, dim3(pblocks), st, s->dev, A, L0, (const unsigned int *)O.order0, O.flags1, gs);
+    RT_LAUNCH_SP(k_primary, stats, param, dim3(pblocks), st, s->dev, A, L0, (const unsigned int *)O.order0, O.flags1, gs, 0);
   }
   unsigned int *order1 = nullptr;
   if (s->dev.has_tree && s->dev.n_lights > 0) {

@@ -190,7 +190,8 @@ RT_HD P2 curve_pt(const DRotational &R, double t, int i, int deg)              /
 // Point2D(t) and TanVec(t) from ONE pass: the level deg-1 pair (b0, b1) of the scheme IS Point2D(t, 0, deg-1) and
 // Point2D(t, 1, deg-1) (same operations on the same control points), TanVec = (b1 - b0) * deg (Bezier.h:36-39) and
 // Point2D(t) = b0 (1-t) + b1 t (Bezier.h:33)
-RT_HD void curve_eval(const DRotational &R, double t, P2 &pt, P2 &tan)
+// (RT: DRotational, or the same in the constant address space -- rt_defer.inc reads a launch's one object through the scalar cache)
+template <class RT> RT_HD void curve_eval(const RT &R, double t, P2 &pt, P2 &tan)
 {
   const int deg = R.n_prof - 1;
   double qu[8], qv[8];
@@ -228,7 +229,7 @@ RT_HD V3 rot_norm(const DRotational &R, double t, double th) { P2 r = curve_norm
 RT_HD V3 rot_ds_dt(const DRotational &R, double t, double th) { P2 dd = curve_tan(R, t); double s, c; rt_sincos(th, &s, &c); return mk(c * dd.u, s * dd.u, dd.v); }
 RT_HD V3 rot_ds_dth(const DRotational &R, double t, double th) { P2 p = curve_pt(R, t, 0, R.n_prof - 1); double s, c; rt_sincos(th, &s, &c); return mk(-(p.u) * s, p.u * c, 0); }
 // S, dS/dt, dS/dtheta at once (what one Newton step needs): one curve pass, one sine, one cosine
-RT_HD void rot_eval(const DRotational &R, double t, double th, V3 &S, V3 &dSt, V3 &dSth)
+template <class RT> RT_HD void rot_eval(const RT &R, double t, double th, V3 &S, V3 &dSt, V3 &dSth)
 {
   P2 p, dd; curve_eval(R, t, p, dd);
   double s, c;
