@@ -124,6 +124,7 @@ struct WaveLds {
   alignas(16) RayLds rays[64];
   unsigned int slot[64];                             // rank among the interested rays of a leaf -> lane
   unsigned long long t_start;                        // k_frame_direct: the wave's start time (its cost orders the next frame's waves)
+  double cam_d[64][3];                               // k_frame_direct: the camera rays' directions across the walks (two unitize = 300 instructions to make again)
 };
 
 // uniform (scalar) copy of a value that is known to be the same in all lanes
@@ -211,7 +212,14 @@ struct RayState {
   unsigned long long pq_mask;         // deferred solves (walk<.., GQ>): the Newton-solved objects (bit pidx) listed by the leaves this ray wanted
 };
 
-__device__ __forceinline__ double safe_inv(double x) { return (fabs(x) < 1e-30) ? ((x < 0) ? -1e30 : 1e30) : 1.0 / x; }
+// 1/x for the box tests only (they decide which nodes are visited, never a result): v_rcp_f64 + one Newton step, ~2^-50 relative -- three
+// instructions instead of the ~30 of an IEEE division, far inside the margins of slab_axis_f (2^-21) and the 1e-7 by which slab()'s boxes are inflated
+__device__ __forceinline__ double safe_inv(double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return (fabs(x) < 1e-30) ? ((x < 0) ? -1e30 : 1e30) : r;
+}
 
 // Margins of the cull (DESIGN.md "cull margins"): with s = 1 + max|scene coordinate| + max|origin coordinate|,
 // the cull's t' differs from the exact t by at most ~7e-10 s when |d.n| >= 1e-6 (rounding of dpl - o.n,

@@ -832,7 +832,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   const bool active = (s_local < A.n_samples) && (tx < A.tiles_x) && (ty < A.tiles_y) && (h < (unsigned)A.cam.W) && (v < (unsigned)A.cam.H) &&
                       (p >= A.pixel_first) && (p < A.pixel_first + A.pixel_count);
   Stats st{};
-  // Camera.h:65-67; evaluated again after the walks instead of being kept alive across them
+  // Camera.h:65-67; the direction waits in LDS across the walks (not in registers: they are what the walks are short of)
   auto camera_ray = [&](V3 &o, V3 &d) {
     unsigned int s2, tx2, ty2; tile_of_wave(A, wave, s2, tx2, ty2);
     const unsigned int h = tx2 * 8 + (lane & 7), v = A.v_lo + ty2 * 8 + (lane >> 3);
@@ -843,6 +843,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   int id; double t, hu = kInfty, hv = kInfty; V3 pt;
   {
     V3 o, d; camera_ray(o, d);
+    stack->cam_d[lane][0] = d.x; stack->cam_d[lane][1] = d.y; stack->cam_d[lane][2] = d.z;
     RayState r; ray_setup(r, o, d, sc.coord_scale);
     if (STATS && active) st.rays++;
     trace_closest<STATS, PARAM>(sc, r, active, stack, st);
@@ -866,7 +867,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   if (active) {
     Col c = mkc(A.bg[0], A.bg[1], A.bg[2]);
     if (hit) {
-      V3 o, d, N; camera_ray(o, d);
+      V3 N; const V3 d = mk(stack->cam_d[lane][0], stack->cam_d[lane][1], stack->cam_d[lane][2]);
       c = local_illumination<PARAM>(sc, d, id, pt, ONE ? &l_one : lum + ((size_t)wave * 64 + lane) * nl, N, hu, hv);
     }
     // the frame is written once and read by nobody on this GPU: streamed past the L2 lines that hold the hierarchy
