@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=0, help="frames in flight per GPU (0 = 4, or 8 from 8 ranks on: one per hardware queue)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N ranks on one GPU: collectives then run on HOST tensors)")
     ap.add_argument("--emulate-world", type=int, default=0, help="one GPU renders rank 0's share of an N-rank run, no collective (tuning aid; not a result)")
+    ap.add_argument("--batch-frames", type=int, default=0, help="C2, N=1: frames per rt_hip_render_whitted_batch_dev launch (0 = one launch per frame, --streams in flight)")
+    ap.add_argument("--force-batch-launch", action="store_true", help="C2, N>1: the batched launch also below 8 ranks (rehearsals of the path)")
+    ap.add_argument("--no-batch-launch", action="store_true", help="C2, N>1: one launch per frame share (8 frames in flight) instead of one rt_hip_render_whitted_batch_dev launch per sub-batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (reference tree, f64 frame, other configs)")
     ap.add_argument("--others", choices=["full", "short"], default="full", help="C3 / C4 / C5 inside the default line: at BASELINE's full sizes (1024 spp, 256 spp, 10 M photons; ~10 s of GPU time together) or cut down and extrapolated")
@@ -232,7 +235,9 @@ def bench_c2(args, D, torch, rta, W):
     emulate = args.emulate_world if world == 1 else 0
     tw = emulate or world                                   # ranks the frame is split over
     tiles_mode = args.mode == "tiles" and tw > 1
-    S = args.streams or (8 if tw >= 8 else 4)   # frames in flight: one per hardware queue (main()); N = 1 measured 2: 5.63, 3: 5.87, 4: 6.11, 6: 5.81, 8: 6.00 Grays/s
+    # measured with --emulate-world N (Grays/s projected, batched / per frame share): N = 2: 14.5 / 16.3, N = 4: 30.1 / 34.3, N = 8 at 4 queues: 60.6 / 48.3
+    batch_launch = tiles_mode and (tw >= 8 or args.force_batch_launch) and not args.no_batch_launch
+    S = args.streams or (8 if (tw >= 8 and args.no_batch_launch) else 4)   # frames in flight: one per hardware queue (main()); N = 1 measured 2: 5.63, 3: 5.87, 4: 6.11, 6: 5.81, 8: 6.00 Grays/s
     F = max(1, args.frames_per_step)
     G = max(S, min(args.sub_batch, F))
     while F % G:
@@ -252,16 +257,23 @@ def bench_c2(args, D, torch, rta, W):
     comm_kind = "none"
     if tiles_mode:
         params_tile = rta.Params(background=(200, 200, 200), frame_format=1, tile_offset=rank, tile_stride=tw)
-        send = [torch.zeros(G * blk, dtype=torch.uint8, device=dev) for _ in range(2)]
-        recv = [torch.zeros(tw * G * blk, dtype=torch.uint8, device=dev) for _ in range(2)] if not emulate else None
-        frames = [torch.zeros((G, npix * 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-        gather_done = [torch.cuda.Event(), torch.cuda.Event()]
+        NSET = S if batch_launch else 2       # buffer sets = sub-batches in flight (batched launches: one per stream / hardware queue)
+        send = [torch.zeros(G * blk, dtype=torch.uint8, device=dev) for _ in range(NSET)]
+        recv = [torch.zeros(tw * G * blk, dtype=torch.uint8, device=dev) for _ in range(NSET)] if not emulate else None
+        frames = [torch.zeros((G, npix * 3), dtype=torch.uint8, device=dev) for _ in range(NSET)]
+        gather_done = [torch.cuda.Event() for _ in range(NSET)]
         if world > 1:
             if args.comm == "abi" and not D.rehearsal:
                 comm = make_abi_comm(rta, ctx, D)
             comm_kind = "rt_hip_comm_all_gather (RCCL)" if comm is not None else ("torch.distributed all_gather_into_tensor (%s)" % args.backend)
     else:
         frames = [torch.zeros((max(2 * S, 2), npix * 3), dtype=torch.uint8, device=dev)]
+    BF = args.batch_frames if (not tiles_mode and world == 1) else 0
+    if BF > 1:
+        while F % BF:
+            BF -= 1
+        G = BF
+        frames = [torch.zeros((S, BF, npix * 3), dtype=torch.uint8, device=dev)]
 
     def gather(set_i):
         """all-gather sub-batch `set_i` and put its G frames into raster order, on the comm stream"""
@@ -285,11 +297,35 @@ def bench_c2(args, D, torch, rta, W):
                                                          C.c_void_p(frames[set_i].data_ptr()), npix * 3, C.c_void_p(comm_stream.cuda_stream)))
             gather_done[set_i].record(comm_stream)
 
+    cam_arrays = {}
+
+    def cam_array(f0):
+        """the cameras of the sub-batch that starts at frame f0, as rt_hip_render_whitted_batch_dev takes them"""
+        key = f0 % 32
+        if key not in cam_arrays:
+            cam_arrays[key] = rta.camera_array([cams[(key + i) % 32] for i in range(G)])
+        return cam_arrays[key]
+
     def one_step(step):
         for j in range(F):
             f = step * F + j
             k = f % S
-            if tiles_mode:
+            if tiles_mode and batch_launch:
+                # the rank's tiles of a whole sub-batch in ONE launch (rt_hip_render_whitted_batch_dev): G x 1/N of a frame fills the GPU like G/N frames
+                if f % G:
+                    continue
+                sb = f // G
+                set_i, k = sb % NSET, sb % S
+                streams[k].wait_event(gather_done[set_i])
+                rta.check(rta.hip.rt_hip_render_whitted_batch_dev(handles[k], cam_array(f), G, params_tile, C.c_void_p(send[set_i].data_ptr()), blk, None, 0,
+                                                                  C.c_void_p(streams[k].cuda_stream)))
+                gather(set_i)
+            elif BF > 1:
+                if f % BF == 0:                # BF whole frames in one launch, the frames' copies of a super-tile side by side on one XCD
+                    k = (f // BF) % S
+                    rta.check(rta.hip.rt_hip_render_whitted_batch_dev(handles[k], cam_array(f), BF, params_full, C.c_void_p(frames[0][k].data_ptr()), npix * 3, None, 0,
+                                                                      C.c_void_p(streams[k].cuda_stream)))
+            elif tiles_mode:
                 set_i, g = (f // G) & 1, f % G
                 if g < S:
                     streams[k].wait_event(gather_done[set_i])      # the gather that last read this buffer set has finished
@@ -329,6 +365,23 @@ def bench_c2(args, D, torch, rta, W):
     D.barrier()
     elapsed = D.reduce(time.perf_counter() - t_start, "max")
     frames_total = F * args.steps * (world if (world > 1 and not tiles_mode) else 1)
+    # outside the timed region: the last sub-batch's gathered pictures against this rank's own whole-frame renders of the same cameras, byte for byte
+    # (what the exchange is for: every rank holds the finished picture)
+    gathered_check = None
+    if tiles_mode and not emulate and args.steps > 0:
+        torch.cuda.synchronize()
+        last_sb = (F * args.steps) // G - 1
+        set_i = last_sb % (NSET if batch_launch else 2)
+        bad = 0
+        full = torch.zeros(npix * 3, dtype=torch.uint8, device=dev)
+        picks = sorted(set([0, G // 2, G - 1]))
+        for g_ in picks:
+            rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cams[(last_sb * G + g_) % 32].raw, params_full, C.c_void_p(full.data_ptr()), None, None))
+            torch.cuda.synchronize()
+            bad += int((frames[set_i][g_] != full).sum().item())
+        bad = int(D.reduce(float(bad), "sum"))
+        gathered_check = {"frames_compared_per_rank": len(picks), "mismatched_bytes_all_ranks": bad,
+                          "what": "the all-gathered Vec3b pictures of the last sub-batch against whole-frame renders of the same cameras on every rank"}
     if rank != 0:
         return None
     ms_per_step = elapsed * 1e3 / args.steps
@@ -346,11 +399,13 @@ def bench_c2(args, D, torch, rta, W):
            "config": {"workload": "C2: synthetic %d-triangle heightfield + ground plane, primary+shadow ray casting %dx%d; a step = %d frames (camera swinging <= 1.8 deg around "
                                   "the C2 view), each to the Vec3b picture of Camera.h:69" % (n_tris, Wd, Ht, F),
                       "triangles": n_tris, "resolution": [Wd, Ht], "frames_per_step": F, "rays_per_frame": int(rays_per_frame), "rays_per_frame_definition": "mean of the kernels' own census over the 32 cameras of the orbit; value = the timed frames' rays, camera by camera, / time",
-                      "ms_per_frame": round(ms_per_step / F, 4), "frames_in_flight": S,
-                      "parallelism": ("one frame split over %d ranks by interleaved 128x64 super-tiles, %d-frame all-gather: %s" % (tw, G, comm_kind)) if tiles_mode
+                      "ms_per_frame": round(ms_per_step / F, 4), "frames_in_flight": S, "frames_per_launch": (BF if BF > 1 else (G if batch_launch else 1)),
+                      "parallelism": ("one frame split over %d ranks by interleaved 128x64 super-tiles, %d-frame all-gather: %s; %s" % (tw, G, comm_kind, "the rank's tiles of a sub-batch in one launch (rt_hip_render_whitted_batch_dev)" if batch_launch else "one launch per frame share")) if tiles_mode
                                      else ("replicas x%d (no collective)" % world if world > 1 else "1 GPU"),
                       "leaf_refine": "library default (own hierarchy, leaves < 20; < 8 for scenes of at most 4096 objects)" if args.leaf_refine is None else args.leaf_refine,
                       "scene_build_s": round(build_s, 2)}}
+    if gathered_check is not None:
+        out["gathered_frame_check"] = gathered_check
     if emulate:
         out["config"]["emulated"] = "rank 0's share of a %d-rank run on one GPU, no collective: value = this rank's rate x %d (a projection, not a result)" % (tw, tw)
     if world > 1 or emulate:
@@ -363,11 +418,15 @@ def bench_c2(args, D, torch, rta, W):
             prof = rta.Profile()
             rta.check(rta.hip.rt_hip_get_profile(raw_scene, C.byref(prof), 1))
             for s_ in range(20):
-                rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cams[s_ % 32].raw, params_tile, C.c_void_p(send[0].data_ptr()), None, sptr))
+                if batch_launch:       # one launch = this rank's shares of G frames: the per-share time is the launch's / G
+                    if s_ < 6:
+                        rta.check(rta.hip.rt_hip_render_whitted_batch_dev(raw_scene, cam_array(s_ * G), G, params_tile, C.c_void_p(send[0].data_ptr()), blk, None, 0, sptr))
+                else:
+                    rta.check(rta.hip.rt_hip_render_whitted_dev(raw_scene, cams[s_ % 32].raw, params_tile, C.c_void_p(send[0].data_ptr()), None, sptr))
             torch.cuda.synchronize()
             rta.check(rta.hip.rt_hip_get_profile(raw_scene, C.byref(prof), 1))
             rta.check(rta.hip.rt_hip_set_profiling(raw_scene, 0))
-            kms = {rta.KERNEL_NAMES[i]: prof.ms[i] / prof.launches[i] for i in range(12) if prof.launches[i]}
+            kms = {rta.KERNEL_NAMES[i]: prof.ms[i] / prof.launches[i] / (G if batch_launch else 1) for i in range(12) if prof.launches[i]}
             dom = max(kms, key=lambda k: kms[k])
             pmc = read_traffic(dom)
             share = float(my_rays) / max(1.0, rays_per_frame)
@@ -677,9 +736,10 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
 
-    # an eighth of a frame fills the GPU's wave slots once and lasts as long as its slowest tile: from 8 ranks on, 8 frames in flight
-    # on 8 hardware queues (HIP's default is 4) instead of 4 on 4; measured with --emulate-world 8: 39.4 -> 44.8 Grays/s projected
-    if max(int(os.environ.get("WORLD_SIZE", "1")), args.emulate_world) >= 8:
+    # an eighth of a frame fills the GPU's wave slots once and lasts as long as its slowest tile.  From 8 ranks on a rank renders its tiles of a whole
+    # sub-batch in one launch (rt_hip_render_whitted_batch_dev; --emulate-world 8 at HIP's default 4 hardware queues: 60.6 Grays/s projected against 48.3
+    # with a launch per frame share); only --no-batch-launch still asks for 8 frames in flight on 8 hardware queues (61.6)
+    if max(int(os.environ.get("WORLD_SIZE", "1")), args.emulate_world) >= 8 and args.no_batch_launch:
         if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
             os.environ["GPU_MAX_HW_QUEUES"] = "8"
     import torch

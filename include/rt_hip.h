@@ -241,6 +241,14 @@ int rt_hip_render_whitted(rt_hip_scene *scene, const rt_hip_camera *cam, const r
 int rt_hip_render_whitted_dev(rt_hip_scene *scene, const rt_hip_camera *cam, const rt_hip_params *params,
                               double *d_rgb, int32_t *d_prim_id, void *stream);
 
+/* CCamera::Render_RayTracer (Camera.h:53-75, depth == 1) for n_frames cameras of one picture size in ONE launch: frame k of cams[k] goes to
+ * (char *)d_rgb + k * rgb_pitch_bytes in params->frame_format, its ids (optional) to d_prim_id + k * id_pitch; the results are those of n_frames calls of
+ * rt_hip_render_whitted_dev.  For the ranks of a multi-GPU run (params->tile_offset / tile_stride): an eighth of a 1080p frame fills the GPU's wave slots
+ * once, the shares of a sub-batch of frames fill it like a whole frame, and the sub-batch is what one all-gather moves anyway.  Scenes without
+ * Bezier / rotational objects, at least one light, 1..64 frames; RT_HIP_EUNSUPPORTED otherwise (render the frames one by one). */
+int rt_hip_render_whitted_batch_dev(rt_hip_scene *scene, const rt_hip_camera *cams, uint32_t n_frames, const rt_hip_params *params,
+                                    void *d_rgb, uint64_t rgb_pitch_bytes, int32_t *d_prim_id, uint64_t id_pitch, void *stream);
+
 /* NO counterpart in the reference.  rt_hip_render_whitted_dev for callers that cannot allocate device memory: code
  * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and same results as
  * rt_hip_render_whitted_dev for a camera of depth 1 (Camera.h:53-75 with depth == 1: closest hit, luminosities, local

@@ -60,6 +60,14 @@ class CameraStruct(C.Structure):
                 ("ver_range", C.c_double), ("resolution", C.c_int32), ("depth", C.c_int32)]
 
 
+def camera_array(cams):
+    """the rt_hip_camera array that rt_hip_render_whitted_batch_dev takes, from Camera objects"""
+    arr = (CameraStruct * len(cams))()
+    for k, c in enumerate(cams):
+        C.memmove(C.byref(arr[k]), c.raw, C.sizeof(CameraStruct))
+    return arr
+
+
 class Params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("background", d3), ("weight_threshold", C.c_double), ("seed", C.c_uint64),
                 ("spp", C.c_uint32), ("lens_radius", C.c_double), ("pixel_first", C.c_uint64), ("pixel_count", C.c_uint64),
@@ -172,6 +180,7 @@ hip.rt_hip_camera_size.argtypes = [C.POINTER(CameraStruct), C.POINTER(C.c_int), 
 hip.rt_hip_render_whitted.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp]
 hip.rt_hip_render_whitted_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
 hip.rt_hip_render_whitted_noalloc.argtypes = [_vp, C.POINTER(CameraStruct), C.POINTER(Params), _vp, _vp, _vp]
+hip.rt_hip_render_whitted_batch_dev.argtypes = [_vp, C.POINTER(CameraStruct), C.c_uint32, C.POINTER(Params), _vp, C.c_uint64, _vp, C.c_uint64, _vp]
 hip.rt_hip_tile_shard_info.argtypes = [C.POINTER(CameraStruct), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
 hip.rt_hip_tiles_to_frame_dev.argtypes = [C.POINTER(CameraStruct), C.c_uint32, _vp, C.c_uint64, C.c_uint32, _vp, _vp]
 hip.rt_hip_tiles_to_frames_dev.argtypes = [C.POINTER(CameraStruct), C.c_uint32, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _vp, C.c_uint64, _vp]

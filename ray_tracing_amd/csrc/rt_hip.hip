@@ -81,6 +81,11 @@ struct alignas(16) PathNode {
 };
 static_assert(sizeof(PathNode) == 128, "PathNode layout");
 
+struct DevCamera {
+  V3 view_pt, start, left, up;
+  int res, W, H, depth;
+};
+
 struct rt_hip_godray;
 struct rt_hip_scene {
   std::atomic<int> refs{1};        // the caller's handle + one per photon map / god ray made from it
@@ -107,6 +112,10 @@ struct rt_hip_scene {
   bool keep_uv = false;            // photon mapping eye pass: keep the (u, v) of every node's hit (k_shade overwrites them)
   bool one_sample = false;         // exactly one light and it takes one shadow ray per point: k_frame_direct has a loop-free form for it
   DevBuf uv[kMaxLevels];
+  // rt_hip_render_whitted_batch_dev: the frames' cameras go to the device through a ring of pinned slots (a copy from pageable memory would make
+  // every call wait for the stream); a slot is reused only after the launch that read it has finished (its event)
+  static constexpr int kBatchSlots = 8, kBatchMax = 64;
+  DevBuf batch_cams; DevCamera *batch_pinned = nullptr; hipEvent_t batch_ev[kBatchSlots] = {}; bool batch_ev_used[kBatchSlots] = {}; unsigned int batch_next = 0;
   // deferred Newton solves (rt_defer.inc): the global pair queue and the solver's per-batch buffers
   DevBuf gq_pairs, gq_counts, gq_res, gq_rays, gq_uvh, gq_seeds, gq_seed_mask, gq_occ;
   bool defer_fits = false;         // every Newton-solved object, profile sample and light sample has a bit in the masks of rt_defer.inc
@@ -551,10 +560,6 @@ extern "C" int rt_hip_debug_read_stamps2(unsigned long long *out, size_t n_waves
   return RT_HIP_OK;
 }
 
-struct DevCamera {
-  V3 view_pt, start, left, up;
-  int res, W, H, depth;
-};
 
 __device__ __forceinline__ void stats_flush(Stats *g, const Stats &s)
 {
@@ -645,6 +650,8 @@ struct RenderArgs {
   uint32_t out_bgr8;                  // the frame goes out as the reference's Vec3b picture (Camera.h:69) instead of f64 R,G,B
   uint64_t n_out, n_primary;          // entries of the output arrays; camera rays of this call
   unsigned int *wave_cost;            // k_frame_direct: where a wave leaves its run time in cycles (NULL: nowhere), see k_cost_order
+  // rt_hip_render_whitted_batch_dev: n_samples frames in one launch -- the "sample" a wave belongs to is its frame; cameras and output pitches per frame
+  const DevCamera *batch_cams; uint64_t batch_rgb_pitch, batch_id_pitch;      // pitches in bytes / in entries
 };
 
 // ---- heavy-first work order --------------------------------------------------------------------
@@ -659,6 +666,10 @@ __device__ __forceinline__ bool ray_meets_box(V3 o, V3 d, const double *bmin, co
   return slab(r, bmin, bmax);
 }
 
+// (BATCH, rt_hip_render_whitted_batch_dev: s_local = the frame, frame-major -- every frame's tiles together, so that one frame's slow last tiles
+// run beside the next frame's first ones.  Measured against it: the frames' copies of a super-tile side by side on one XCD, to share its L2 --
+// no gain at N = 1, 10 % slower on half and quarter frames: the slow tiles of all frames then end the launch together.)
+template <bool BATCH = false>
 __device__ __forceinline__ void tile_of_wave(const RenderArgs &A, unsigned int wave, unsigned int &s_local, unsigned int &tx, unsigned int &ty)
 {
   const unsigned int sx = (A.tiles_x + 15) / 16;
@@ -815,7 +826,8 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
 // A depth-1 frame in ONE launch (Camera.h:53-75 with depth == 1): camera ray + closest hit as in k_primary, the
 // luminosities as in k_shadow, the local illumination, the frame.  Nothing goes through a level array, and the
 // low-occupancy tail of the primary pass disappears into the shadow walks of the same waves.
-template <bool STATS, bool PARAM, bool ONE = false>
+// BATCH: the tiles of several frames in one launch (rt_hip_render_whitted_batch_dev): a wave's frame is what tile_of_wave calls its sample.
+template <bool STATS, bool PARAM, bool ONE = false, bool BATCH = false>
 __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWAVES) k_frame_direct(DevScene sc, RenderArgs A, const unsigned int *order, double *lum,
                                                                           RenderCounters *cnt, Stats *gstats, double *rgb, int32_t *prim_id)
 {
@@ -825,7 +837,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   const unsigned int wave = order ? (unsigned int)uni((int)order[slot]) : slot;
   const unsigned int lane = threadIdx.x & 63;
   if (A.wave_cost && lane == 0) stack->t_start = __builtin_readcyclecounter();     // kept in LDS: no register lives across the walks for it
-  unsigned int s_local, tx, ty; tile_of_wave(A, wave, s_local, tx, ty);
+  unsigned int s_local, tx, ty; tile_of_wave<BATCH>(A, wave, s_local, tx, ty);
   const unsigned int h = tx * 8 + (lane & 7);
   const unsigned int v = A.v_lo + ty * 8 + (lane >> 3);
   const uint64_t p = (uint64_t)v * A.cam.W + h;
@@ -834,10 +846,11 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   Stats st{};
   // Camera.h:65-67; the direction waits in LDS across the walks (not in registers: they are what the walks are short of)
   auto camera_ray = [&](V3 &o, V3 &d) {
-    unsigned int s2, tx2, ty2; tile_of_wave(A, wave, s2, tx2, ty2);
+    unsigned int s2, tx2, ty2; tile_of_wave<BATCH>(A, wave, s2, tx2, ty2);
     const unsigned int h = tx2 * 8 + (lane & 7), v = A.v_lo + ty2 * 8 + (lane >> 3);
-    V3 cur = A.cam.start - A.cam.left * (double(h) / double(A.cam.res)) - A.cam.up * (double(v) / double(A.cam.res));
-    o = A.cam.view_pt;
+    const DevCamera &cam = BATCH ? A.batch_cams[uni((int)(s2 < A.n_samples ? s2 : 0u))] : A.cam;
+    V3 cur = cam.start - cam.left * (double(h) / double(cam.res)) - cam.up * (double(v) / double(cam.res));
+    o = cam.view_pt;
     d = unitize(unitize(cur - o));
   };
   int id; double t, hu = kInfty, hv = kInfty; V3 pt;
@@ -859,7 +872,7 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   const int nl = ONE ? 1 : sc.n_lights;      // ONE: one light of one sample, so neither loop exists and nothing is hoisted across the walk
   for (int li = 0; li < nl; li++) {
     const DLight &L = sc.lights[li];
-    RngKey key; key.seed = A.seed; key.pixel = pix; key.sample = A.sample_first + s_local; key.path = 1;
+    RngKey key; key.seed = A.seed; key.pixel = pix; key.sample = A.sample_first + (BATCH ? 0u : s_local); key.path = 1;
     double l = light_luminosity<STATS, PARAM, ONE>(sc, L, li, pt, hit, key, stack, st);
     if (ONE) l_one = l;
     else if (hit) lum[((size_t)wave * 64 + lane) * nl + li] = l;
@@ -872,8 +885,14 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
     }
     // the frame is written once and read by nobody on this GPU: streamed past the L2 lines that hold the hierarchy
     const uint64_t q = out_slot(A, pix % (unsigned)A.cam.W, pix / (unsigned)A.cam.W);
+    if (BATCH) {
+      unsigned int s2, tx2, ty2; tile_of_wave<BATCH>(A, wave, s2, tx2, ty2);
+      store_colour(A, (double *)((unsigned char *)rgb + (uint64_t)s2 * A.batch_rgb_pitch), q, c, true);
+      if (prim_id) __builtin_nontemporal_store(id, &prim_id[(uint64_t)s2 * A.batch_id_pitch + q]);
+    } else {
     store_colour(A, rgb, q, c, true);
     if (prim_id) __builtin_nontemporal_store(id, &prim_id[q]);
+    }
   }
   // shadow rays of this wave: the count per shaded point does not depend on the walks
   unsigned long long per_hit = 0;
@@ -1201,6 +1220,8 @@ extern "C" int rt_hip_scene_destroy(rt_hip_scene *s)
   for (auto &b : s->levels) b.release();
   for (auto &b : s->uv) b.release();
   s->counter.release(); s->staging.release(); s->lum.release(); s->wave_cost.release(); s->order.release(); s->aa_maps.release(); s->aa_edges.release(); s->aa_mask.release();
+  for (DevBuf *b : {&s->gq_pairs, &s->gq_counts, &s->gq_res, &s->gq_rays, &s->gq_uvh, &s->gq_seeds, &s->gq_seed_mask, &s->gq_occ, &s->batch_cams}) b->release();
+  if (s->batch_pinned) { (void)hipHostFree(s->batch_pinned); for (hipEvent_t e : s->batch_ev) if (e) (void)hipEventDestroy(e); }
   ctx_release(s->ctx);
   delete s;
   return RT_HIP_OK;
@@ -1893,7 +1914,7 @@ static int fill_args(rt_hip_scene *s, const rt_hip_camera *cam, const rt_hip_par
 {
   if (!s || !P) return fail(RT_HIP_EINVAL, "NULL argument");
   if (P->struct_size != sizeof(rt_hip_params)) return fail(RT_HIP_EINVAL, "rt_hip_params.struct_size mismatch");
-  A->wave_cost = nullptr;
+  A->wave_cost = nullptr; A->batch_cams = nullptr; A->batch_rgb_pitch = 0; A->batch_id_pitch = 0;
   int rc = camera_setup(cam, &A->cam); if (rc) return rc;
   const uint64_t total = (uint64_t)A->cam.W * A->cam.H;
   A->pixel_first = P->pixel_count ? P->pixel_first : 0;
@@ -1960,6 +1981,64 @@ extern "C" int rt_hip_render_whitted_dev(rt_hip_scene *s, const rt_hip_camera *c
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(A.n_out)), dim3(RT_BLOCK), 0, st, (const PathNode *)s->levels[0].p, A, 1.0, 0, d_rgb, d_prim_id);
   }
   HIP_TRY(hipGetLastError());
+  return RT_HIP_OK;
+}
+
+// Several depth-1 frames of ONE tiling in one launch: frame k from cams[k] to d_rgb + k * rgb_pitch_bytes (and d_prim_id + k * id_pitch).  A rank of an
+// N-GPU run renders 1/N of every frame -- an eighth of a 1080p frame is 4,080 waves, one round of the GPU's wave slots, so a launch per frame lasts as long
+// as its slowest tile and throughput has to come from launches in flight; the shares of a sub-batch of frames in one launch fill the GPU like a whole frame.
+extern "C" int rt_hip_render_whitted_batch_dev(rt_hip_scene *s, const rt_hip_camera *cams, uint32_t n_frames, const rt_hip_params *P, void *d_rgb,
+                                                uint64_t rgb_pitch_bytes, int32_t *d_prim_id, uint64_t id_pitch, void *stream)
+{
+  if (!cams || n_frames == 0 || n_frames > 64) return fail(RT_HIP_EINVAL, "1 to 64 frames per batch");
+  RenderArgs A; int rc = fill_args(s, &cams[0], P, &A); if (rc) return rc;
+  if (!d_rgb) return fail(RT_HIP_EINVAL, "rgb is NULL");
+  if (P->collect_stats) return fail(RT_HIP_EUNSUPPORTED, "no statistics build of the batched frame kernel");
+  if (s->dev.has_param || s->dev.n_lights <= 0 || s->god || s->keep_uv)
+    return fail(RT_HIP_EUNSUPPORTED, "batched frames: scenes of triangles / planes / spheres / circles with at least one light (use rt_hip_render_whitted_dev per frame)");
+  A.out_bgr8 = (P->frame_format == RT_HIP_FRAME_BGR8) ? 1u : 0u;
+  const uint64_t frame_bytes = A.n_out * (A.out_bgr8 ? 3u : 24u);
+  if (n_frames > 1 && (rgb_pitch_bytes < frame_bytes || (d_prim_id && id_pitch < A.n_out))) return fail(RT_HIP_EINVAL, "frame pitch smaller than a frame");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  if (!s->batch_pinned) {
+    HIP_TRY(hipHostMalloc((void **)&s->batch_pinned, sizeof(DevCamera) * rt_hip_scene::kBatchSlots * rt_hip_scene::kBatchMax, hipHostMallocDefault));
+    for (int k = 0; k < rt_hip_scene::kBatchSlots; k++) HIP_TRY(hipEventCreateWithFlags(&s->batch_ev[k], hipEventDisableTiming));
+  }
+  rc = s->batch_cams.ensure(sizeof(DevCamera) * rt_hip_scene::kBatchSlots * rt_hip_scene::kBatchMax); if (rc) return rc;
+  const unsigned int slot = s->batch_next++ % rt_hip_scene::kBatchSlots;
+  if (s->batch_ev_used[slot]) HIP_TRY(hipEventSynchronize(s->batch_ev[slot]));
+  DevCamera *host_cams = s->batch_pinned + (size_t)slot * rt_hip_scene::kBatchMax;
+  DevCamera *dev_cams = (DevCamera *)s->batch_cams.p + (size_t)slot * rt_hip_scene::kBatchMax;
+  for (uint32_t k = 0; k < n_frames; k++) {
+    DevCamera &c = host_cams[k];
+    rc = camera_setup(&cams[k], &c); if (rc) return rc;
+    if (c.depth > 1) return fail(RT_HIP_EUNSUPPORTED, "batched frames are depth-1 frames (Camera.h:53-75 with depth == 1)");
+    if (c.W != A.cam.W || c.H != A.cam.H || c.res != A.cam.res) return fail(RT_HIP_EINVAL, "the cameras of a batch share one picture size");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  rc = s->counter.ensure(sizeof(RenderCounters)); if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(s->counter.p, 0, sizeof(RenderCounters), st));
+  HIP_TRY(hipMemcpyAsync(dev_cams, host_cams, n_frames * sizeof(DevCamera), hipMemcpyHostToDevice, st));
+  s->last_rays = 0; s->last_shadow = 0; s->last_counters = s->counter.p;
+  if (A.n_st == 0) return RT_HIP_OK;
+  A.n_samples = n_frames; A.batch_cams = dev_cams; A.batch_rgb_pitch = rgb_pitch_bytes; A.batch_id_pitch = id_pitch;
+  const uint64_t n_waves = level0_waves(A);
+  if (n_waves * 64 > 0x7FFFFFFFull) return fail(RT_HIP_EINVAL, "batch size out of range");
+  const bool one = frame_direct_one(s, false);
+  if (!one) { rc = s->lum.ensure((size_t)n_waves * 64 * s->dev.n_lights * sizeof(double)); if (rc) return rc; }
+  {
+    ProfScope ps(s, RT_HIP_K_FRAME_DIRECT, st);
+    const unsigned int pblocks = (unsigned int)(n_waves / RT_WAVES);
+    if (one) hipLaunchKernelGGL((k_frame_direct<false, false, true, true>), dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, (const unsigned int *)nullptr, (double *)nullptr,
+                                (RenderCounters *)s->counter.p, (Stats *)nullptr, (double *)d_rgb, d_prim_id);
+    else hipLaunchKernelGGL((k_frame_direct<false, false, false, true>), dim3(pblocks), dim3(RT_BLOCK), 0, st, s->dev, A, (const unsigned int *)nullptr, (double *)s->lum.p,
+                            (RenderCounters *)s->counter.p, (Stats *)nullptr, (double *)d_rgb, d_prim_id);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->batch_ev[slot], st)); s->batch_ev_used[slot] = true;
+  for (int lv = 0; lv < rt_hip_scene::kMaxLevels; lv++) s->last_n_level[lv] = 0;
+  s->last_level = 0;
+  s->last_rays += A.n_primary * n_frames;
   return RT_HIP_OK;
 }
 

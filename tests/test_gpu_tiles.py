@@ -231,3 +231,51 @@ def test_repeated_frames_on_one_handle_are_identical(ctx, monkeypatch):
     rta.check(rta.hip.rt_hip_last_wave_costs(g.device(ctx), C.c_void_p(cost.ctypes.data), nw.value, C.byref(nw)))
     assert (cost > 0).all() and cost.max() > 4 * np.median(cost)        # the tiles on the mesh take several times the background tiles' time
     assert rta.hip.rt_hip_last_wave_costs(g.device(ctx), C.c_void_p(cost.ctypes.data), 5, C.byref(nw)) == -1
+
+
+@pytest.mark.parametrize("stride", [1, 3, 8])
+def test_batched_frames_equal_single_frames(ctx, stride):
+    """rt_hip_render_whitted_batch_dev: the tile shares (or whole frames, stride 1) of five cameras in one launch against five calls of
+    rt_hip_render_whitted_dev, as the Vec3b picture and as doubles + ids, with one light of one sample (the loop-free kernel) and with the
+    area light (luminosities through the lum array); pitches larger than a frame are respected"""
+    import torch
+    import ray_tracing_amd as rta
+    for light in ("point", "point_area"):
+        g, _ = scenes.build_icosahedron(material="plastic", light=light, extra_sphere=True, oracle=False)
+        cams = [rta.Camera(**dict(scenes.C1_CAMERA, hor=4.1, ver=2.9, res=100, depth=1, view=(-10 + 0.3 * k, 0.2 * k, 1.5))) for k in range(5)]
+        arr = rta.camera_array(cams)
+        total, per = C.c_uint32(), C.c_uint32()
+        rta.check(rta.hip.rt_hip_tile_shard_info(cams[0].raw, stride, C.byref(total), C.byref(per)))
+        n_out = per.value * 8192 if stride > 1 else cams[0].width * cams[0].height
+        for fmt, elem, dt in ((1, 3, torch.uint8), (0, 24, torch.float64)):
+            for rank in range(min(stride, 2)):
+                kw = dict(tile_offset=rank, tile_stride=stride) if stride > 1 else {}
+                p = rta.Params(background=(200, 200, 200), frame_format=fmt, seed=11, **kw)
+                pitch = n_out * elem + 64
+                batch = torch.full((5, pitch), 9, dtype=torch.uint8, device="cuda")
+                bids = torch.full((5, n_out + 16), -7, dtype=torch.int32, device="cuda")
+                rta.check(rta.hip.rt_hip_render_whitted_batch_dev(g.device(ctx), arr, 5, p, C.c_void_p(batch.data_ptr()), pitch, C.c_void_p(bids.data_ptr()), n_out + 16, None))
+                torch.cuda.synchronize()
+                a, b = C.c_uint64(), C.c_uint64()
+                rta.check(rta.hip.rt_hip_last_ray_count(g.device(ctx), C.byref(a), C.byref(b)))
+                rays = 0
+                for k in range(5):
+                    one = torch.full((n_out * elem,), 9, dtype=torch.uint8, device="cuda")
+                    ids = torch.full((n_out,), -7, dtype=torch.int32, device="cuda")
+                    rta.check(rta.hip.rt_hip_render_whitted_dev(g.device(ctx), cams[k].raw, p, C.c_void_p(one.data_ptr()), C.c_void_p(ids.data_ptr()), None))
+                    torch.cuda.synchronize()
+                    a1, b1 = C.c_uint64(), C.c_uint64()
+                    rta.check(rta.hip.rt_hip_last_ray_count(g.device(ctx), C.byref(a1), C.byref(b1)))
+                    rays += a1.value
+                    assert torch.equal(batch[k, :n_out * elem], one), (light, stride, fmt, rank, k)
+                    assert torch.equal(bids[k, :n_out], ids)
+                assert (batch[:, n_out * elem:] == 9).all() and (bids[:, n_out:] == -7).all()
+                assert a.value == rays
+    # refused: deeper cameras, cameras of another size
+    deep = rta.Camera(**dict(scenes.C1_CAMERA, hor=4.1, ver=2.9, res=100, depth=2))
+    arr2 = rta.camera_array([cams[0], deep])
+    p = rta.Params(background=(200, 200, 200))
+    assert rta.hip.rt_hip_render_whitted_batch_dev(g.device(ctx), arr2, 2, p, C.c_void_p(8), 1 << 30, None, 0, None) == -4      # RT_HIP_EUNSUPPORTED
+    other = rta.Camera(**dict(scenes.C1_CAMERA, hor=4.0, ver=2.9, res=100, depth=1))
+    arr3 = rta.camera_array([cams[0], other])
+    assert rta.hip.rt_hip_render_whitted_batch_dev(g.device(ctx), arr3, 2, p, C.c_void_p(8), 1 << 30, None, 0, None) == -1      # RT_HIP_EINVAL
