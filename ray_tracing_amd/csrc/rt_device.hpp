@@ -344,6 +344,16 @@ __device__ __forceinline__ bool param_may_matter(const RayState &r, const double
   return slab(q, pmin, pmax);
 }
 
+// the same for a patch, piece by piece: its accepted hits lie in one of the 16 sub-patch hull boxes (rt_param.hpp: param_prune_box)
+__device__ __forceinline__ bool bez_may_matter(const RayState &r, const DBezier &Z, double t_max)
+{
+  RayState q = r; q.bound = t_max;
+  if (!slab(q, Z.pmin, Z.pmax)) return false;
+  bool any = false;
+  for (int k = 0; k < 16; k++) any = any || slab(q, Z.sub[k], Z.sub[k] + 3);
+  return any;
+}
+
 // direct-to-LDS copy of `bytes` (rounded up to 1 KiB pieces, at most RT_CHUNK_BYTES) from a 16-byte
 // aligned global address; every lane moves 16 bytes per instruction (wave-uniform LDS base + lane*16).
 __device__ __forceinline__ void stage_chunk(const unsigned char *src, unsigned char *lds, int bytes)
@@ -789,7 +799,7 @@ __device__ __forceinline__ void walk(const DevScene &sc, RayState &r, bool activ
                 bool push = lane_on && r.mb_id != prim;
                 if (push) r.mb_id = prim;
                 if (type == 5) { const DRotational &R = sc.rotationals[sc.obj_index[prim]]; push = push && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, r.bound) && rot_shells_may_matter(R, r.o, r.d, r.bound); }
-                else { const DBezier &Z = sc.beziers[sc.obj_index[prim]]; push = push && param_may_matter(r, Z.pmin, Z.pmax, r.bound); }
+                else { const DBezier &Z = sc.beziers[sc.obj_index[prim]]; push = push && bez_may_matter(r, Z, r.bound); }
                 nq = pairs_push(PQ, nq, push, prim);
                 solve_pairs(64);
                 continue;
@@ -952,7 +962,7 @@ __device__ __forceinline__ void trace_closest(const DevScene &sc, RayState &r, b
           const double t_max = r.best_id >= 0 ? r.best_t : kMiss;
           bool want;
           if (type == 5) { const DRotational &R = sc.rotationals[k]; want = active && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, t_max) && rot_shells_may_matter(R, r.o, r.d, t_max); }
-          else { const DBezier &Z = sc.beziers[k]; want = active && param_may_matter(r, Z.pmin, Z.pmax, t_max); }
+          else { const DBezier &Z = sc.beziers[k]; want = active && bez_may_matter(r, Z, t_max); }
           if (STATS && active) st.exact_tests++;
           if (want) r.pq_mask |= 1ull << (k + (type == 6 ? sc.n_rot : 0));
           continue;
@@ -1139,7 +1149,7 @@ __device__ __forceinline__ uint32_t gq_push_closest(const DevScene &sc, const Ra
     const bool bez = pidx >= sc.n_rot;
     if (sc.has_tree) {
       if (!bez) { const DRotational &R = sc.rotationals[pidx]; want = want && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, t_max) && rot_shells_may_matter(R, r.o, r.d, t_max); }
-      else { const DBezier &Z = sc.beziers[pidx - sc.n_rot]; want = want && param_may_matter(r, Z.pmin, Z.pmax, t_max); }
+      else { const DBezier &Z = sc.beziers[pidx - sc.n_rot]; want = want && bez_may_matter(r, Z, t_max); }
     }
     head = gq_push(sc, want, pidx, ray, (uint32_t)pidx, head);
   }
@@ -1154,7 +1164,7 @@ __device__ __forceinline__ void gq_push_occluded(const DevScene &sc, const RaySt
     if (ballot64(want) == 0ull) continue;
     const bool bez = pidx >= sc.n_rot;
     if (!bez) { const DRotational &R = sc.rotationals[pidx]; want = want && !ref_box_miss(R.bmin, R.bmax, r.o, r.d) && param_may_matter(r, R.pmin, R.pmax, t_limit) && rot_shells_may_matter(R, r.o, r.d, t_limit); }
-    else { const DBezier &Z = sc.beziers[pidx - sc.n_rot]; want = want && param_may_matter(r, Z.pmin, Z.pmax, t_limit); }
+    else { const DBezier &Z = sc.beziers[pidx - sc.n_rot]; want = want && bez_may_matter(r, Z, t_limit); }
     (void)gq_push(sc, want, pidx, ray, tag_hi | (uint32_t)pidx, 0xFFFFFFFFu);
   }
 }

@@ -18,6 +18,7 @@ struct DBezier {
   double c[4][4][3]; double center[3];     // controlPts[i][j], center
   double pmin[3], pmax[3];
   double seed[25][3];                      // Point3D(i/4, j/4) + center of the 5x5 Newton seeds (Object.h:1094-1098): the same for every ray
+  double sub[16][6];                       // param_prune_box: hull boxes (min xyz, max xyz) of the 4 x 4 sub-patches, grown like pmin / pmax
 };
 struct DBezierCtrl { double c[4][4][3]; double center[3]; };    // what the Newton steps read: a lane's private copy
 struct DRotational {
@@ -253,6 +254,29 @@ inline void param_prune_box(DBezier &B)
   for (int i = 0; i <= 4; i++) for (int j = 0; j <= 4; j++) {
     const V3 p = bez_point(B, i * (1 / double(4)), j * (1 / double(4))) + center;      // as bezier_hit computes it (no contraction: host == device)
     B.seed[i * 5 + j][0] = p.x; B.seed[i * 5 + j][1] = p.y; B.seed[i * 5 + j][2] = p.z;
+  }
+  // The same argument piece by piece: the surface over [a/4, (a+1)/4] x [b/4, (b+1)/4] lies in the convex hull of THAT piece's control net (the
+  // blossom of the cubics at the piece's end parameters), so an accepted iterate lies in one of the 16 hull boxes grown by the pad.  A curved
+  // sheet fills a small part of its one box; rays through the rest of it run 25 seeds to find nothing.
+  auto blossom = [](const double p[4], double t1, double t2, double t3) {
+    const double a0 = p[0] * (1 - t1) + p[1] * t1, a1 = p[1] * (1 - t1) + p[2] * t1, a2 = p[2] * (1 - t1) + p[3] * t1;
+    const double b0 = a0 * (1 - t2) + a1 * t2, b1 = a1 * (1 - t2) + a2 * t2;
+    return b0 * (1 - t3) + b1 * t3;
+  };
+  auto segment = [&](const double p[4], double a, double b, double q[4]) {
+    q[0] = blossom(p, a, a, a); q[1] = blossom(p, a, a, b); q[2] = blossom(p, a, b, b); q[3] = blossom(p, b, b, b);
+  };
+  for (int pa = 0; pa < 4; pa++) for (int pb = 0; pb < 4; pb++) {
+    const double u0 = pa / 4.0, u1 = (pa + 1) / 4.0, v0 = pb / 4.0, v1 = (pb + 1) / 4.0;
+    double *S = B.sub[pa * 4 + pb];
+    for (int a = 0; a < 3; a++) {
+      double tmp[4][4], net[4][4];
+      for (int j = 0; j < 4; j++) { const double col[4] = {B.c[0][j][a], B.c[1][j][a], B.c[2][j][a], B.c[3][j][a]}; double q[4]; segment(col, u0, u1, q); for (int i = 0; i < 4; i++) tmp[i][j] = q[i]; }
+      for (int i = 0; i < 4; i++) { double q[4]; segment(tmp[i], v0, v1, q); for (int j = 0; j < 4; j++) net[i][j] = q[j]; }
+      double mn = 1e300, mx = -1e300;
+      for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { mn = dmin(mn, net[i][j]); mx = dmax(mx, net[i][j]); }
+      S[a] = mn + B.center[a] - pad; S[3 + a] = mx + B.center[a] + pad;
+    }
   }
 }
 inline void param_prune_box(DRotational &R)
