@@ -666,7 +666,7 @@ def other_config(name, args, D, torch, rta, W, ctx, short, once=False):
                "samples_per_pixel_timed": spp_run, "rays": int(rays), "s_per_step": round(dt, 5), "Mrays_per_s": round(rays / dt / 1e6, 1),
                "s_per_frame_at_256spp": round(dt / spp_run * spp_total, 2), "extrapolated": spp_run != spp_total,
                "parallelism": "row split + all-gather" if world > 1 else "1 GPU"}
-        kernel = "k_primary_list"
+        kernel = ["k_newton_bez", "k_primary_list"]       # deferred Newton solves (the default) / the in-place kernels (RT_HIP_PARAM_DEFER=0)
     else:
         g = W.build_wine(W.product_stage, cups="layout", light="area5").sides[0][0]
         assert g.num_objects == 24
@@ -694,8 +694,19 @@ def other_config(name, args, D, torch, rta, W, ctx, short, once=False):
                "passes_timed": passes, "s_per_step": round(dt, 4), "photon_segments_per_pass": int(segs / passes), "rays": int(segs / passes),
                "Mrays_per_s": round(segs / passes / dt / 1e6, 2), "s_per_pass_at_10M_photons": round(dt * 1e7 / info["photons_per_pass"], 3),
                "extrapolated": info["photons_per_pass"] != 10000000, "parallelism": "photon split + all-reduce of (M, tau) per hit point" if world > 1 else "1 GPU"}
-        kernel = "k_ppm_bounce"           # the per-bounce launches (their counters: averages over the launches of one pass, instructions and cycles alike)
-    pmc = read_traffic(kernel + ":" + name) or read_traffic(kernel)
+        kernel = ["k_newton_rot", "k_ppm_bounce"]        # the solver's launches of eye pass and photon passes / the in-place per-bounce kernels
+    if isinstance(kernel, str):
+        kernel = [kernel]
+    if os.environ.get("RT_HIP_PARAM_DEFER", "") == "0":
+        kernel = kernel[-1:]
+    pmc = {}
+    for kname in kernel:
+        pmc = read_traffic(kname + ":" + name) or read_traffic(kname)
+        if pmc:
+            kernel = kname
+            break
+    else:
+        kernel = kernel[0]
     if pmc.get("SQ_INSTS_VALU") and pmc.get("kernel_cycles"):
         # (both figures from the same profiled run: instructions and GRBM cycles of the kernel; the mix weights the cycles per instruction)
         share = pmc.get("valu_f64_share")
