@@ -626,10 +626,17 @@ def other_config(name, args, D, torch, rta, W, ctx, short, once=False):
         D.barrier()
         dt = D.reduce((time.perf_counter() - t) / reps, "max")
         rays = D.reduce(last_rays(rta, raw)[0] if cnt else 0, "sum")
+        pv = C.c_uint64(0)
+        if cnt:
+            rta.check(rta.hip.rt_hip_last_proved_shadow_rays(raw, C.byref(pv)))
+        proved = D.reduce(pv.value, "sum")
         res = {"workload": "C3: Layout3_Icosahedron, depth of field (Camera.h:171-199) %dx%d, 10x10 area light (100 shadow rays per lens sample), lens radius 0.1" % (cam.width, cam.height),
                "samples_per_pixel_timed": spp_run, "rays": int(rays), "s_per_step": round(dt, 5), "Mrays_per_s": round(rays / dt / 1e6, 1),
                "s_per_frame_at_1024spp": round(dt / spp_run * spp_total, 2), "extrapolated": spp_run != spp_total,
-               "parallelism": "sample split + all-reduce(sum) of the f64 frame" if world > 1 else "1 GPU"}
+               "parallelism": "sample split + all-reduce(sum) of the f64 frame" if world > 1 else "1 GPU",
+               # `rays` = the rays the reference makes for this frame (primary + every light sample of every hit).  Of them, the shadow rays of points
+               # that area_light_all_clear proves unoccluded are counted but not traced:
+               "shadow_rays_proved_clear": int(proved), "rays_traced": int(rays - proved), "Mrays_per_s_traced": round((rays - proved) / dt / 1e6, 1)}
         kernel = "k_shadow"
     elif name == "C4":
         g = W.build_paper(W.product_stage).sides[0][0]

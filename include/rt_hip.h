@@ -424,6 +424,10 @@ int rt_hip_get_profile(rt_hip_scene *scene, rt_hip_profile *out, int reset);
 
 /* number of rays (closest-hit + occlusion queries) issued by the last render call on this scene */
 int rt_hip_last_ray_count(rt_hip_scene *scene, uint64_t *rays, uint64_t *shadow_rays);
+/* Diagnostic, no counterpart in the reference: of the shadow rays rt_hip_last_ray_count reports for the last render call, those the library did
+ * not trace because it proved their points unoccluded from the point and the area light's rectangle alone (area_light_all_clear;
+ * CAreaLight::luminosity, Light.h:126-162, makes every one of them).  They are counted as rays: the figure says how many. */
+int rt_hip_last_proved_shadow_rays(rt_hip_scene *scene, uint64_t *n);
 /* Diagnostic, no counterpart in the reference: shader-clock cycles every wave (8x8-pixel tile, in the library's tile order: 128x64-pixel
  * super-tiles row by row, 16x8 tiles inside each) of this handle's last depth-1 frame was resident - the figures that order the next frame's
  * work (rt_hip_scene_share).  *n_waves = number of entries (0: no such frame yet); out may be NULL to ask for the size.  Synchronises the device. */

@@ -225,6 +225,7 @@ hip.rt_hip_scene_destroy.argtypes = [_vp]
 hip.rt_hip_set_profiling.argtypes = [_vp, C.c_int]
 hip.rt_hip_get_profile.argtypes = [_vp, C.POINTER(Profile), C.c_int]
 hip.rt_hip_last_ray_count.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+hip.rt_hip_last_proved_shadow_rays.argtypes = [_vp, C.POINTER(C.c_uint64)]
 hip.rt_hip_last_wave_costs.argtypes = [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]
 
 

@@ -100,6 +100,7 @@ struct DevScene {
   double coord_scale;                           // max |coordinate| of finite geometry
   double rbmin[3], rbmax[3];                    // root box (inflated); only used to order work, never for results
   float rbf_min[3], rbf_max[3];                 // the same in FP32, rounded outward: shadow rays that miss it skip the walk (trace_occluded)
+  int32_t lit_skip;                             // area_light_all_clear() in front of an area light's sample loop (RT_HIP_LIT_SKIP=0 at scene creation: off)
 };
 
 // One deferred solve: `ray` names the ray (index of its node / photon), tag = pidx | sample << 8 | light << 20 (shadow rays), next = the
@@ -1388,9 +1389,53 @@ struct RngKey { uint64_t seed; uint32_t pixel, sample, path; };
 // Light.h:62-69 / 87-94, CAreaLight::luminosity (Light.h:126-162) and luminosity_BSPTree
 // (Scene.h:436-455).  Every shadow query is a wave-packet occlusion walk; point and parallel lights are
 // the one-sample case of the same loop.
+// Can NO shadow ray from pt towards an area light's samples be occluded?  Conservative (true = certainly none), from pt and the light's
+// rectangle alone -- every sample target lies in R = [lp.x -+ (sn + 1) rr] x [lp.y -+ (sn + 1) rr] x {lp.z} (Light.h:126-140: cell corner + random(rr)):
+//  * finite objects: all of them lie in the root box.  A plane through pt that has R on its non-negative side and the whole box below
+//    -delta separates every ray pt + s (q - pt), s >= 0, q in R, from the box: tried for the four planes through pt and an edge of R, and for
+//    the plane z = pt.z.  delta = 1e-6 S^2 (S = 1 + the largest coordinate in play) is ten orders above the rounding of these products and far
+//    above the eps = 1e-8 by which the reference's triangle test reaches beyond a triangle;
+//  * the infinite planes (the root's own objects), CInftyPlane::FirstInterPt as plane_t restates it: t = a / (n.d), a = -(D + n.pt).  With
+//    g = n.(q - pt) of one strict sign over R: a of the other sign (or zero) gives t <= 0 -- no hit; a of the same sign but so small that
+//    |a| / min|n.d| < eps / 4 gives t < eps -- no hit (the point lies ON the plane: the floor under a floor point); a ray that rounds to
+//    parallel returns 0 or nothing, and t = 0 never satisfies the predicate of Scene.h:449.  Anything else: not clear.
+// A wave whose points are all clear adds up the light's samples without making a single ray (C3: the floor and the wall away from the solid).
+__device__ __forceinline__ bool area_light_all_clear(const DevScene &sc, V3 lp, int sn, double rr, V3 pt)
+{
+  const double hs = (sn + 2) * rr;
+  const double cx0 = lp.x - hs - pt.x, cx1 = lp.x + hs - pt.x, cy0 = lp.y - hs - pt.y, cy1 = lp.y + hs - pt.y, dz = lp.z - pt.z;
+  const double S = 1.0 + sc.coord_scale + dmax(dmax(fabs(pt.x), fabs(pt.y)), fabs(pt.z)) + dmax(dmax(fabs(lp.x), fabs(lp.y)), fabs(lp.z)) + hs;
+  const double delta = 1e-6 * S * S;
+  const double bx0 = (double)sc.rbf_min[0] - pt.x, bx1 = (double)sc.rbf_max[0] - pt.x, by0 = (double)sc.rbf_min[1] - pt.y, by1 = (double)sc.rbf_max[1] - pt.y;
+  const double bz0 = (double)sc.rbf_min[2] - pt.z, bz1 = (double)sc.rbf_max[2] - pt.z;
+  const double adz = fabs(dz), sg = (dz >= 0.0) ? 1.0 : -1.0;
+  bool clear = false;
+  { const double k = -sg * cx0; clear = clear || (adz * bx1 + dmax(k * bz0, k * bz1) < -delta); }     // normal  sg (dz, 0, -cx0): R at x >= its low edge
+  { const double k = sg * cx1;  clear = clear || (-adz * bx0 + dmax(k * bz0, k * bz1) < -delta); }    // normal -sg (dz, 0, -cx1)
+  { const double k = -sg * cy0; clear = clear || (adz * by1 + dmax(k * bz0, k * bz1) < -delta); }
+  { const double k = sg * cy1;  clear = clear || (-adz * by0 + dmax(k * bz0, k * bz1) < -delta); }
+  clear = clear || ((dz >= 0.0 ? bz1 : -bz0) < -1e-6 * S);                                              // the box wholly on the other side of z = pt.z
+  if (!clear) return false;
+  const double lmax = sqrt(dmax(cx0 * cx0, cx1 * cx1) + dmax(cy0 * cy0, cy1 * cy1) + dz * dz);
+  for (int i = 0; i < sc.n_root_objs; i++) {
+    const int id = uni(sc.root_objs[i]);
+    if (uni((int)sc.obj_type[id]) != 4) return false;
+    const DPlane &P = sc.planes[sc.obj_index[id]];
+    const V3 p0 = mk(P.p0[0], P.p0[1], P.p0[2]), n = mk(P.n[0], P.n[1], P.n[2]);
+    const double D = -dot(p0, n), a = -(D + dot(n, pt));                                                // as plane_t has them
+    const double gz = n.z * dz;
+    const double gmin = gz + dmin(n.x * cx0, n.x * cx1) + dmin(n.y * cy0, n.y * cy1), gmax = gz + dmax(n.x * cx0, n.x * cx1) + dmax(n.y * cy0, n.y * cy1);
+    const double gm = 1e-9 * S * (fabs(n.x) + fabs(n.y) + fabs(n.z));
+    double sgn, gl;
+    if (gmin > gm) { sgn = 1.0; gl = gmin; } else if (gmax < -gm) { sgn = -1.0; gl = -gmax; } else return false;
+    if (a * sgn > 0.0 && !(fabs(a) * lmax < 0.25 * kEps * gl)) return false;
+  }
+  return true;
+}
+
 template <bool STATS, bool PARAM, bool ONE = false>
 __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLight &L, int li, V3 pt, bool active,
-                                                   const RngKey &key, WaveLds *lds, Stats &st)
+                                                   const RngKey &key, WaveLds *lds, Stats &st, unsigned long long *proved = nullptr)
 {
   const V3 lp = mk(L.p[0], L.p[1], L.p[2]);
   const int type = uni(L.type);
@@ -1400,6 +1445,14 @@ __device__ __forceinline__ double light_luminosity(const DevScene &sc, const DLi
   const V3 O = mk(lp.x - sn * rr, lp.y - sn * rr, lp.z);
   const double per = area ? L.lum_per_sample : L.lum;
   double lum = 0;
+  if constexpr (!ONE && !STATS && !PARAM) {
+    if (area && sn > 1 && sc.has_tree && sc.lit_skip && !sc.has_param) {
+      const bool clear = !active || area_light_all_clear(sc, lp, sn, rr, pt);
+      if (proved && active && clear) *proved += (unsigned long long)(sn * sn);                        // census: counted as shadow rays, not traced
+      if (__ballot(!clear) == 0ull) { for (int s = 0; s < sn * sn; s++) lum += per; return lum; }      // (the same sum, sample by sample)
+      active = active && !clear;     // in a mixed wave the clear points sit out the walks (every sample counts for them: `occ` stays false)
+    }
+  }
   const double scale = ray_origin_scale(pt, sc.coord_scale);      // every shadow ray of this point starts at pt
   for (int s = 0; s < sn * sn; s++) {
     const int i = s / sn, j = s % sn;

@@ -134,7 +134,8 @@ struct rt_hip_scene {
 
 // level_n[lv]: nodes of ray-tree level lv of the render in flight, counted on the device (k_shade appends level lv + 1) so that the host
 // never waits for a level to learn the size of the next
-struct RenderCounters { unsigned int queue_count; unsigned int pad; unsigned long long rays; unsigned long long shadow_rays; unsigned int level_n[16]; };
+struct RenderCounters { unsigned int queue_count; unsigned int pad; unsigned long long rays; unsigned long long shadow_rays; unsigned int level_n[16];
+                        unsigned long long shadow_rays_proved; };   // of shadow_rays: not traced, their points proved unoccluded (area_light_all_clear)
 // number of nodes a level kernel works on: the host's bound (cap), cut to the device's count when one is given
 __device__ __forceinline__ unsigned int level_count(const unsigned int *n_dev, unsigned int cap)
 { if (!n_dev) return cap; const unsigned int n = *n_dev; return n < cap ? n : cap; }
@@ -869,11 +870,12 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   // what lives across the light walks is pt, id and the pixel number; the rest is made again where it is used
   const uint32_t pix = (uint32_t)p;
   double l_one = 0;                           // ONE: the one luminosity stays in a register
+  unsigned long long my_proved = 0;
   const int nl = ONE ? 1 : sc.n_lights;      // ONE: one light of one sample, so neither loop exists and nothing is hoisted across the walk
   for (int li = 0; li < nl; li++) {
     const DLight &L = sc.lights[li];
     RngKey key; key.seed = A.seed; key.pixel = pix; key.sample = A.sample_first + (BATCH ? 0u : s_local); key.path = 1;
-    double l = light_luminosity<STATS, PARAM, ONE>(sc, L, li, pt, hit, key, stack, st);
+    double l = light_luminosity<STATS, PARAM, ONE>(sc, L, li, pt, hit, key, stack, st, ONE ? nullptr : &my_proved);
     if (ONE) l_one = l;
     else if (hit) lum[((size_t)wave * 64 + lane) * nl + li] = l;
   }
@@ -902,6 +904,12 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   }
   const unsigned long long my_shadow = per_hit * (unsigned long long)__popcll(__ballot(hit));
   if (lane == 0 && my_shadow) atomicAdd(&cnt->shadow_rays, my_shadow);
+  if (!ONE) {
+    if (__ballot(my_proved != 0ull) != 0ull) {
+      for (int off = 32; off > 0; off >>= 1) my_proved += __shfl_down(my_proved, off, 64);
+      if (lane == 0) atomicAdd(&cnt->shadow_rays_proved, my_proved);
+    }
+  }
   if (STATS) stats_flush(gstats, st);
   if (A.wave_cost && lane == 0) {
     const unsigned long long dt = __builtin_readcyclecounter() - stack->t_start;
@@ -966,15 +974,19 @@ __global__ void __launch_bounds__(RT_BLOCK, PARAM ? RT_PARAM_MINWAVES : RT_MINWA
   }
   const bool hit = in_range && id >= 0;
   const V3 pt = hit ? (o + d * t) : mk(0, 0, 0);     // ray.beginPt() + ray.direction() * t
-  unsigned long long my_shadow = 0;
+  unsigned long long my_shadow = 0, my_proved = 0;
   for (int li = 0; li < sc.n_lights; li++) {
     const DLight &L = sc.lights[li];
-    double l = light_luminosity<STATS, PARAM>(sc, L, li, pt, hit, key, stack, st);
+    double l = light_luminosity<STATS, PARAM>(sc, L, li, pt, hit, key, stack, st, &my_proved);
     if (hit) { lum[(size_t)i * sc.n_lights + li] = l; my_shadow += (L.type == 102) ? (unsigned long long)L.sample_num * L.sample_num : 1ull; }
   }
   // ray census (always on: it is what rt_hip_last_ray_count reports)
   for (int off = 32; off > 0; off >>= 1) my_shadow += __shfl_down(my_shadow, off, 64);
   if ((threadIdx.x & 63) == 0 && my_shadow) atomicAdd(&cnt->shadow_rays, my_shadow);
+  if (__ballot(my_proved != 0ull) != 0ull) {
+    for (int off = 32; off > 0; off >>= 1) my_proved += __shfl_down(my_proved, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&cnt->shadow_rays_proved, my_proved);
+  }
 #ifdef RT_STAMPS
   stamp(i >> 6, 1);
 #endif
@@ -1437,6 +1449,7 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
   D.root = root_ref; D.has_tree = has_tree ? 1 : 0;
   D.n_root_objs = (int32_t)root_objs.size(); D.n_objects = (int32_t)d->n_objects; D.n_lights = (int32_t)d->n_lights;
   D.ambient = d->ambient; D.coord_scale = cs;
+  { const char *e = std::getenv("RT_HIP_LIT_SKIP"); D.lit_skip = (e && e[0] == '0') ? 0 : 1; }
   s->n_nodes = (uint32_t)B.pairs.size(); s->n_leaves = B.n_leaves; s->n_cull = B.n_recs; s->max_depth = B.max_depth;
   *out = s;
   return RT_HIP_OK;
@@ -2123,8 +2136,12 @@ extern "C" int rt_hip_tiles_to_frame_dev(const rt_hip_camera *cam, uint32_t tile
 static int focusing_batches(rt_hip_scene *s, RenderArgs A, bool stats, uint32_t spp, uint32_t s_first, uint32_t s_count, double *d_rgb, hipStream_t st)
 {
   int rc;
-  // batch the samples so that one level-0 array stays near 1 GiB
-  uint64_t per = (1ull << 30) / ((uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * 64 * sizeof(PathNode));
+  // batch the samples so that one level-0 array stays near 8 GiB (RT_HIP_DOF_BATCH_GIB: another budget).  With the all-clear test most waves of
+  // a launch cost next to nothing and the launch lasts as long as the waves around the geometry: C3 at 1024 spp 3.96 s with 1 GiB batches (4 samples),
+  // 3.34 / 2.85 / 2.75 s with 2 / 4 / 8 GiB, no further gain beyond
+  uint64_t budget = 8ull << 30;
+  { const char *e = std::getenv("RT_HIP_DOF_BATCH_GIB"); if (e && std::atoi(e) > 0) budget = (uint64_t)std::min(64, std::atoi(e)) << 30; }
+  uint64_t per = budget / ((uint64_t)((A.tiles_x + 15) / 16) * ((A.tiles_y + 7) / 8) * 128 * 64 * sizeof(PathNode));
   uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per, 64));
   for (uint32_t done = 0; done < s_count; done += batch) {
     A.sample_first = s_first + done; A.n_samples = std::min(batch, s_count - done);
@@ -2189,6 +2206,18 @@ extern "C" int rt_hip_last_ray_count(rt_hip_scene *s, uint64_t *rays, uint64_t *
   if (src) HIP_TRY(hipMemcpy(&c, src, sizeof c, hipMemcpyDeviceToHost));
   if (rays) *rays = s->last_rays + c.rays + c.shadow_rays;
   if (shadow_rays) *shadow_rays = c.shadow_rays;
+  return RT_HIP_OK;
+}
+
+extern "C" int rt_hip_last_proved_shadow_rays(rt_hip_scene *s, uint64_t *n)
+{
+  if (!s || !n) return fail(RT_HIP_EINVAL, "NULL argument");
+  HIP_TRY(hipSetDevice(s->ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  RenderCounters c{};
+  const void *src = s->last_counters ? s->last_counters : s->counter.p;
+  if (src) HIP_TRY(hipMemcpy(&c, src, sizeof c, hipMemcpyDeviceToHost));
+  *n = c.shadow_rays_proved;
   return RT_HIP_OK;
 }
 
