@@ -76,6 +76,7 @@ struct DMaterial { double reflW, refrW, RI, diff, spec, shiness, emissive, ambie
 struct DLight { int32_t type, sample_num; double p[3], lum, len, lum_per_sample; };
 struct DTexture { const uint8_t *bgr; int32_t rows, cols; };           // cv::Mat CV_8UC3: bgr[(row * cols + col) * 3 + {B,G,R}]
 
+#define RT_COVER_BOXES 16
 struct DevScene {
   const DPairF *pairs; const unsigned char *leaf_stream;
   ChildRef root; int32_t has_tree;              // has_tree == 0: CScene::FirstInterPt over all objects
@@ -101,6 +102,8 @@ struct DevScene {
   double rbmin[3], rbmax[3];                    // root box (inflated); only used to order work, never for results
   float rbf_min[3], rbf_max[3];                 // the same in FP32, rounded outward: shadow rays that miss it skip the walk (trace_occluded)
   int32_t lit_skip;                             // area_light_all_clear() in front of an area light's sample loop (RT_HIP_LIT_SKIP=0 at scene creation: off)
+  // a cover of all finite geometry by the boxes of a cut through the top of the hierarchy (the root box alone when the root is a leaf): FP32, rounded outward
+  int32_t n_cover; float cover_min[RT_COVER_BOXES][3], cover_max[RT_COVER_BOXES][3];
 };
 
 // One deferred solve: `ray` names the ray (index of its node / photon), tag = pidx | sample << 8 | light << 20 (shadow rays), next = the
@@ -1391,9 +1394,9 @@ struct RngKey { uint64_t seed; uint32_t pixel, sample, path; };
 // the one-sample case of the same loop.
 // Can NO shadow ray from pt towards an area light's samples be occluded?  Conservative (true = certainly none), from pt and the light's
 // rectangle alone -- every sample target lies in R = [lp.x -+ (sn + 1) rr] x [lp.y -+ (sn + 1) rr] x {lp.z} (Light.h:126-140: cell corner + random(rr)):
-//  * finite objects: all of them lie in the root box.  A plane through pt that has R on its non-negative side and the whole box below
-//    -delta separates every ray pt + s (q - pt), s >= 0, q in R, from the box: tried for the four planes through pt and an edge of R, and for
-//    the plane z = pt.z.  delta = 1e-6 S^2 (S = 1 + the largest coordinate in play) is ten orders above the rounding of these products and far
+//  * finite objects: all of them lie in the boxes of a cut through the top of the hierarchy (DevScene::cover_*, at most 16; the root box when
+//    the root is a leaf).  A plane through pt that has R on its non-negative side and a whole box below -delta separates every ray
+//    pt + s (q - pt), s >= 0, q in R, from that box: tried, box by box, for the four planes through pt and an edge of R, and for the plane z = pt.z.  delta = 1e-6 S^2 (S = 1 + the largest coordinate in play) is ten orders above the rounding of these products and far
 //    above the eps = 1e-8 by which the reference's triangle test reaches beyond a triangle;
 //  * the infinite planes (the root's own objects), CInftyPlane::FirstInterPt as plane_t restates it: t = a / (n.d), a = -(D + n.pt).  With
 //    g = n.(q - pt) of one strict sign over R: a of the other sign (or zero) gives t <= 0 -- no hit; a of the same sign but so small that
@@ -1406,16 +1409,19 @@ __device__ __forceinline__ bool area_light_all_clear(const DevScene &sc, V3 lp, 
   const double cx0 = lp.x - hs - pt.x, cx1 = lp.x + hs - pt.x, cy0 = lp.y - hs - pt.y, cy1 = lp.y + hs - pt.y, dz = lp.z - pt.z;
   const double S = 1.0 + sc.coord_scale + dmax(dmax(fabs(pt.x), fabs(pt.y)), fabs(pt.z)) + dmax(dmax(fabs(lp.x), fabs(lp.y)), fabs(lp.z)) + hs;
   const double delta = 1e-6 * S * S;
-  const double bx0 = (double)sc.rbf_min[0] - pt.x, bx1 = (double)sc.rbf_max[0] - pt.x, by0 = (double)sc.rbf_min[1] - pt.y, by1 = (double)sc.rbf_max[1] - pt.y;
-  const double bz0 = (double)sc.rbf_min[2] - pt.z, bz1 = (double)sc.rbf_max[2] - pt.z;
   const double adz = fabs(dz), sg = (dz >= 0.0) ? 1.0 : -1.0;
-  bool clear = false;
-  { const double k = -sg * cx0; clear = clear || (adz * bx1 + dmax(k * bz0, k * bz1) < -delta); }     // normal  sg (dz, 0, -cx0): R at x >= its low edge
-  { const double k = sg * cx1;  clear = clear || (-adz * bx0 + dmax(k * bz0, k * bz1) < -delta); }    // normal -sg (dz, 0, -cx1)
-  { const double k = -sg * cy0; clear = clear || (adz * by1 + dmax(k * bz0, k * bz1) < -delta); }
-  { const double k = sg * cy1;  clear = clear || (-adz * by0 + dmax(k * bz0, k * bz1) < -delta); }
-  clear = clear || ((dz >= 0.0 ? bz1 : -bz0) < -1e-6 * S);                                              // the box wholly on the other side of z = pt.z
-  if (!clear) return false;
+  const double kx0 = -sg * cx0, kx1 = sg * cx1, ky0 = -sg * cy0, ky1 = sg * cy1;
+  // every box of the cover (sc.n_cover boxes that hold all finite objects between them) must be cut off by one of the five planes
+  for (int c = 0; c < sc.n_cover; c++) {
+    const double bx0 = (double)sc.cover_min[c][0] - pt.x, bx1 = (double)sc.cover_max[c][0] - pt.x, by0 = (double)sc.cover_min[c][1] - pt.y, by1 = (double)sc.cover_max[c][1] - pt.y;
+    const double bz0 = (double)sc.cover_min[c][2] - pt.z, bz1 = (double)sc.cover_max[c][2] - pt.z;
+    bool clear = adz * bx1 + dmax(kx0 * bz0, kx0 * bz1) < -delta;                                      // normal  sg (dz, 0, -cx0): R at x >= its low edge
+    clear = clear || (-adz * bx0 + dmax(kx1 * bz0, kx1 * bz1) < -delta);                              // normal -sg (dz, 0, -cx1)
+    clear = clear || (adz * by1 + dmax(ky0 * bz0, ky0 * bz1) < -delta);
+    clear = clear || (-adz * by0 + dmax(ky1 * bz0, ky1 * bz1) < -delta);
+    clear = clear || ((dz >= 0.0 ? bz1 : -bz0) < -1e-6 * S);                                          // the box wholly on the other side of z = pt.z
+    if (!clear) return false;
+  }
   const double lmax = sqrt(dmax(cx0 * cx0, cx1 * cx1) + dmax(cy0 * cy0, cy1 * cy1) + dz * dz);
   for (int i = 0; i < sc.n_root_objs; i++) {
     const int id = uni(sc.root_objs[i]);

@@ -1336,6 +1336,30 @@ extern "C" int rt_hip_scene_create(rt_hip_ctx *ctx, const rt_hip_scene_desc *d, 
       for (int a = 0; a < 3; a++) { s->dev.rbmin[a] = root.box.mn[a]; s->dev.rbmax[a] = root.box.mx[a]; s->dev.rbf_min[a] = Builder::f32_down(root.box.mn[a]); s->dev.rbf_max[a] = Builder::f32_up(root.box.mx[a]); }
       for (int a = 0; a < 3; a++) cs = std::max(cs, std::max(std::fabs(root.box.mn[a]), std::fabs(root.box.mx[a])));
     }
+    // the cover for area_light_all_clear: start from the root box, open the inner node with the largest surface until RT_COVER_BOXES boxes are there
+    {
+      struct CB { double mn[3], mx[3]; ChildRef ref; };
+      std::vector<CB> cover;
+      if (!root.empty) {
+        CB c0; for (int a = 0; a < 3; a++) { c0.mn[a] = root.box.mn[a]; c0.mx[a] = root.box.mx[a]; } c0.ref = root_ref; cover.push_back(c0);
+        while (cover.size() < (size_t)RT_COVER_BOXES) {
+          int pick = -1; double best = -1;
+          for (size_t k = 0; k < cover.size(); k++) {
+            if (cover[k].ref.i0 < 0 || (size_t)cover[k].ref.i0 >= B.pairs.size()) continue;
+            const double ex = cover[k].mx[0] - cover[k].mn[0], ey = cover[k].mx[1] - cover[k].mn[1], ez = cover[k].mx[2] - cover[k].mn[2];
+            const double area = ex * ey + ey * ez + ez * ex;
+            if (area > best) { best = area; pick = (int)k; }
+          }
+          if (pick < 0) break;
+          const DPair P = B.pairs[cover[pick].ref.i0];
+          CB l, r; for (int a = 0; a < 3; a++) { l.mn[a] = P.lmin[a]; l.mx[a] = P.lmax[a]; r.mn[a] = P.rmin[a]; r.mx[a] = P.rmax[a]; } l.ref = P.l; r.ref = P.r;
+          cover[pick] = l; cover.push_back(r);
+        }
+      }
+      s->dev.n_cover = (int32_t)cover.size();
+      for (size_t k = 0; k < cover.size(); k++) for (int a = 0; a < 3; a++) {
+        s->dev.cover_min[k][a] = Builder::f32_down(cover[k].mn[a]); s->dev.cover_max[k][a] = Builder::f32_up(cover[k].mx[a]); }
+    }
     if (B.pairs.empty()) B.pairs.emplace_back();
     // slack so that the fixed-size direct-to-LDS chunk loads never read past the allocation
     B.stream.resize(B.stream.size() + 2 * RT_CHUNK_BYTES, 0);

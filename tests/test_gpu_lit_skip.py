@@ -109,3 +109,23 @@ def test_light_inside_the_scene_box_height(ctx):
 
 def test_two_lights(ctx):
     _both_forms_and_oracle(ctx, lambda oracle: scenes.build_icosahedron(material="plastic", light="two", oracle=oracle), "lit-skip two lights")
+
+
+def test_depth_of_field_and_a_deeper_ray_tree_both_forms_identical(ctx):
+    """the per-level kernels (k_shadow) instead of the one-launch depth-1 frame: lens samples, and a metal solid at depth 3"""
+    import ray_tracing_amd as rta
+    c = dict(scenes.C3_CAMERA); c["res"] = 40
+    c3 = dict(c); c3["depth"] = 3
+    out = []
+    for on in (False, True):
+        with _Skip(on):
+            g, _ = scenes.build_icosahedron(material="metal", light="area10", oracle=False)
+            cam = rta.Camera(**c)
+            n = cam.width * cam.height
+            dof = np.zeros((n, 3))
+            rta.check(rta.hip.rt_hip_render_focusing(g.device(ctx), cam.raw, rta.Params(background=(200, 200, 200), seed=5, spp=6, lens_radius=0.1), dof.ctypes.data))
+            deep = _frame(rta, ctx, g, rta.Camera(**c3), background=(200, 200, 200), seed=5)
+            out.append((dof, deep[0], deep[1]))
+    assert out[0][0].std() > 1.0
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
