@@ -20,8 +20,8 @@ def read(tag):
     rta.check(f(z.ctypes.data, 1))
     out[tag] = {"patch_wave_steps_x64": int(z[0]), "patch_lane_steps": int(z[1]), "patch_efficiency": float(z[1]) / max(1.0, float(z[0])),
                 "revolution_wave_steps_x64": int(z[2]), "revolution_lane_steps": int(z[3]), "revolution_efficiency": float(z[3]) / max(1.0, float(z[2])),
-                "patch_efficiency_if_lanes_ran_free": float(z[5]) / max(1.0, float(z[4])), "revolution_efficiency_if_lanes_ran_free": float(z[7]) / max(1.0, float(z[6])),
-                "revolution_wave_steps_x64_if_lanes_ran_free": int(z[6]), "patch_wave_steps_x64_if_lanes_ran_free": int(z[4])}
+                "patch_pairs": int(z[4]), "patch_pairs_with_a_root": int(z[5]), "revolution_pairs": int(z[6]), "revolution_pairs_with_a_root": int(z[7]),
+                "patch_steps_per_pair": float(z[1]) / max(1.0, float(z[4])), "revolution_steps_per_pair": float(z[3]) / max(1.0, float(z[6]))}
     print(tag, json.dumps(out[tag]))
 
 
