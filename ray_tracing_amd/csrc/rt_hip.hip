@@ -534,8 +534,8 @@ __device__ __forceinline__ void stamp(unsigned int wave, int which, int kernel =
 extern "C" int rt_hip_debug_read_solve_steps(unsigned long long *out, int reset)
 {
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_solve_steps), 8 * 8, 0, hipMemcpyDeviceToHost));
-  if (reset) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_solve_steps), z, sizeof z, 0, hipMemcpyHostToDevice)); }
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_solve_steps), 16 * 8, 0, hipMemcpyDeviceToHost));
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rt::g_solve_steps), z, sizeof z, 0, hipMemcpyHostToDevice)); }
   return RT_HIP_OK;
 }
 #endif

@@ -35,7 +35,8 @@ constexpr int kMaxStepNum = 10;          // Object.h:831
 // Diagnostic build only (-DRT_SOLVE_STATS): Newton steps as the waves run them ([0] patch, [2] revolution: steps x 64) and as the lanes
 // need them ([1], [3]: lanes active in each step); the ratio is the lock-step efficiency of the solve loops.
 #if defined(RT_SOLVE_STATS) && defined(__HIPCC__)
-__device__ unsigned long long g_solve_steps[8];   // deferred solver (rt_defer.inc): [4] patch pairs, [5] of them with a root, [6] / [7] the same for surfaces of revolution
+__device__ unsigned long long g_solve_steps[16];  // deferred solver (rt_defer.inc): [4] patch pairs, [5] of them with a root, [6] / [7] the same for surfaces of revolution;
+                                                  // [8] / [9] pairs / roots of closest-hit queries, [10] / [11] of occlusion queries (both object kinds)
 #endif
 #if defined(RT_SOLVE_STATS) && defined(__HIP_DEVICE_COMPILE__)
 #define RT_SOLVE_LANE_STEPS(h) (h).steps++;
