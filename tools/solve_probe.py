@@ -21,7 +21,7 @@ def read(tag):
     out[tag] = {"patch_wave_steps_x64": int(z[0]), "patch_lane_steps": int(z[1]), "patch_efficiency": float(z[1]) / max(1.0, float(z[0])),
                 "revolution_wave_steps_x64": int(z[2]), "revolution_lane_steps": int(z[3]), "revolution_efficiency": float(z[3]) / max(1.0, float(z[2])),
                 "patch_pairs": int(z[4]), "patch_pairs_with_a_root": int(z[5]), "revolution_pairs": int(z[6]), "revolution_pairs_with_a_root": int(z[7]),
-                "closest_hit_pairs": int(z[8]), "closest_hit_pairs_with_a_root": int(z[9]), "occlusion_pairs": int(z[10]), "occlusion_pairs_with_a_root": int(z[11]),
+                "closest_hit_pairs": int(z[8]), "closest_hit_pairs_with_a_root": int(z[9]), "occlusion_pairs": int(z[10]), "occlusion_pairs_with_a_root": int(z[11]), "occlusion_pairs_settled_by_an_earlier_batch": int(z[12]),
                 "patch_steps_per_pair": float(z[1]) / max(1.0, float(z[4])), "revolution_steps_per_pair": float(z[3]) / max(1.0, float(z[6]))}
     print(tag, json.dumps(out[tag]))
 
